@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: K=24 r=1/2 Viterbi streaming decode on MI355X.
+
+Workload (BASELINE.json configs[1]): one 1e7-symbol synthetic soft-symbol stream per GPU, decoded
+with the semantics of `vdecode -d 200` (one trellis step + decodebit(200,0) per bit), inputs
+resident in HBM before the timed region, decoded bits left in HBM.  A "step" = one full pass of
+that stream (init + 5e6 trellis steps + 5e6 tracebacks).  N>1: every rank decodes its own
+independent stream (segments shard one-per-GPU, no collective in the data path) -> weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      : HBM roofline of the ACS kernel (algorithmic 34 603 008 B per trellis step),
+                  average launch time from HIP events recorded on the decoder's own stream
+  cpu_baseline  : the reference's SSE2 decoder (oracle/_ref, built from /root/reference in the
+                  build container) on ONE host core, bounded sample
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+ALG_BYTES_PER_STEP = (1 << 23) * 2 * 2 + (1 << 23) // 8          # read + write u16 metrics + decisions
+HBM_PEAK_GBS = 8000.0
+
+
+def load_pkg():
+    name = "isee3_decoder_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    pkgdir = os.path.join(ROOT, "isee3-decoder_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkgdir, "__init__.py"),
+                                                  submodule_search_locations=[pkgdir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(nbits_sample):
+    """Reference SSE2 decoder on one host core (falls back to the oracle port restatement)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    syms = np.full(2 * nbits_sample, 128, np.uint8)
+    rng = np.random.default_rng(1)
+    syms = rng.integers(0, 256, 2 * nbits_sample, dtype=np.uint8)
+    if orc.have_ref():
+        d = orc.RefV224(256, "sse2")
+        kind, what = "reference", "viterbi224_sse2.c (oracle/_ref), update_viterbi224_blk"
+    else:
+        os.environ["OMP_NUM_THREADS"] = "1"
+        d = orc.OracleV224(256, orc.FAST)
+        kind, what = "port", "oracle FAST engine (port semantics, SSE2), 1 thread"
+    d.init(0)
+    d.update(syms[:512], 256)                     # touch memory
+    d.init(0)
+    t0 = time.perf_counter()
+    done = 0
+    while done < nbits_sample:
+        n = min(256, nbits_sample - done)
+        d.update(syms[2 * done:2 * (done + n)], n)
+        done += n
+    dt = time.perf_counter() - t0
+    d.close()
+    return {"value": round(2 * nbits_sample / dt / 1e6, 6), "unit": "Msymbols/s", "cores": 1, "kind": kind,
+            "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nbits_sample, what, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--symbols", type=int, default=10_000_000)
+    ap.add_argument("--delay", type=int, default=200)
+    ap.add_argument("--engine", type=int, default=-1)
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cpu-bits", type=int, default=6000)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pkg = load_pkg()
+    pkg.v224_lib().v224hip_set_device(local)
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+
+    nbits = a.symbols // 2
+    syms, bits, noise_mask = synth.coded_stream(1000 + rank, nbits, 3.0, 24.0, 1.0)
+    d_syms = pkg.DeviceBuffer.from_numpy(syms)
+    d_out = pkg.DeviceBuffer(nbits)
+
+    dec0 = pkg.Viterbi224(8, a.engine, a.k)           # probe defaults
+    chunk = a.chunk or 1020
+    dec0.close()
+    dec = pkg.Viterbi224(a.delay + 2 * chunk, a.engine, a.k)
+    dec.set_option("chunk", chunk)
+
+    def step():
+        dec.init(0)
+        dec.stream_decode_dev(d_syms, nbits, a.delay, d_out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    dec.set_option("profile", 8)
+    dec.acs_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    launches, ms, steps_timed = dec.acs_stats()
+    dec.set_option("profile", 0)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: decoded bits equal sent bits away from the noise blocks (does not replace tests/)
+    out = d_out.to_numpy(np.uint8)
+    dec_bits = out[a.delay + 23:]
+    ref_bits = bits[1:1 + len(dec_bits)]
+    clean = np.ones(len(dec_bits), bool)
+    nz = np.flatnonzero(noise_mask[::2])
+    for i in nz[:: 256]:
+        lo = max(0, i - 1200); clean[lo:i + 1200] = False
+    ber = float(np.mean(dec_bits[clean] != ref_bits[clean])) if clean.any() else -1.0
+
+    if rank == 0:
+        total_syms = 2 * nbits * world * a.steps
+        avg_ms = ms / launches if launches else float("nan")
+        steps_per_launch = steps_timed / launches if launches else 0
+        ach = ALG_BYTES_PER_STEP * steps_per_launch / (avg_ms * 1e-3) / 1e9 if launches else None
+        res = {
+            "metric": "Viterbi K=24 Msymbols/s",
+            "value": round(total_syms / dt / 1e6, 4), "unit": "Msymbols/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "viterbi224 ACS+chainback streaming, 2^23 states, 8-bit soft syms, "
+                                   "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
+                       "engine": "fused" if dec.L.v224hip_stream_chunk(dec.h) and a.engine != 0 else "simple",
+                       "k": a.k or int(os.environ.get("V224HIP_K", "6")), "chunk_bits": chunk,
+                       "segments_per_gpu": 1, "parallelism": "segments x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
+                         "traffic": None,
+                         "kernel": "k_acs_fused" if a.engine != 0 else "k_acs_simple",
+                         "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
+                         "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "launches_timed": launches},
+            "check": {"ber_clean": ber, "bits": int(clean.sum())},
+        }
+        if world == 1 and not a.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_bits)
+            res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

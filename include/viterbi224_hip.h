@@ -1,0 +1,72 @@
+/* viterbi224_hip.h -- extensions of libviterbi224_hip.so beyond the reference's nine-function
+ * API (include/viterbi224.h).  Everything here is plain C-ABI: pointers, sizes, ints.
+ *
+ * Why they exist: the reference's own streaming caller runs ONE trellis step per call and a
+ * 200-step traceback per decoded bit (vdecode.c:145,152).  A GPU wants the same work handed over
+ * in blocks; these entry points do exactly what a loop of update_viterbi224_blk(p,s,1) +
+ * decodebit_viterbi224(p,delay,0) would do, for a whole block, with identical results.
+ */
+#ifndef VITERBI224_HIP_H
+#define VITERBI224_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "viterbi224.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* engines (option "engine"): */
+#define V224HIP_ENGINE_SIMPLE 0  /* one trellis step per launch, decisions in the port's bit order */
+#define V224HIP_ENGINE_FUSED  1  /* register-resident radix-2^k passes, permuted decision layout  */
+
+/* Number of HIP devices visible / select the device used by subsequent create calls of this
+ * thread (default: device 0, or $V224HIP_DEVICE).  -1 on error. */
+int v224hip_device_count(void);
+int v224hip_set_device(int dev);
+
+/* create_viterbi224 with explicit engine (-1 = default / $V224HIP_ENGINE) and fused stage count
+ * (0 = default / $V224HIP_K).  NULL on failure; v224hip_last_error() says why. */
+void *v224hip_create(int len, int engine, int k);
+const char *v224hip_last_error(void);
+
+/* update_viterbi224_blk with the 2*nbits symbols already resident in device memory. */
+int v224hip_update_dev(void *p, const uint8_t *d_syms, int nbits);
+
+/* Streaming block decode == for each of nbits: update(1 bit); out[i] = decodebit(delay, 0).
+ * out[i] is 0/1, or 0xff while fewer than `delay` steps have run since init (vdecode.c:151-158
+ * suppresses exactly those).  Needs len >= delay + 2*v224hip_stream_chunk(p).
+ * `syms`/`out` are host buffers in the first form, device buffers in the _dev form. */
+int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, uint8_t *out);
+int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbits, int delay, uint8_t *d_out);
+int v224hip_stream_chunk(void *p);                 /* bits per internal chunk (option "chunk") */
+
+/* Generic option setter: "chunk" (bits per stream chunk), "profile" (1: time every ACS launch
+ * with HIP events on the decoder's stream).  -1 on unknown key / bad value. */
+int v224hip_set_option(void *p, const char *key, long value);
+
+/* Block until all enqueued work of this decoder has finished. */
+int v224hip_sync(void *p);
+
+/* ACS launch statistics since the last reset (needs option "profile"=1): number of ACS launches,
+ * their summed device time in ms (hipEventElapsedTime per launch), trellis steps they covered. */
+int v224hip_acs_stats(void *p, unsigned long long *launches, double *total_ms,
+                      unsigned long long *steps, int reset);
+
+/* Test/inspection: decision row `row` of the ring converted to the port's layout (bit s of the
+ * 1 MiB row = decision for new state s, port.c:13,183), and the current path metrics minus their
+ * minimum as uint32[2^23].  Host buffers. */
+int v224hip_export_row(void *p, int row, uint8_t *out_1MiB);
+int v224hip_export_metrics(void *p, uint32_t *out_8M);
+
+/* Device memory helpers so that a C (non-HIP) caller can keep buffers resident in HBM. */
+void *v224hip_dev_alloc(size_t bytes);
+void  v224hip_dev_free(void *d);
+int   v224hip_h2d(void *d_dst, const void *h_src, size_t bytes);
+int   v224hip_d2h(void *h_dst, const void *d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,239 @@
+"""isee3-decoder_amd -- MI355X-native hot path of the ISEE-3/ICE receive chain.
+
+This package is a thin ctypes face over the C-ABI shared libraries built from csrc/ (hand-written
+HIP for gfx950).  There is NO CPU fallback: if a library is missing, or no GPU is visible when a
+decoder is created, the call raises.
+
+The directory name contains a hyphen, so load it with `tests/conftest.py::load_pkg()` /
+`importlib` under the module name ``isee3_decoder_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+BIN_DIR = os.path.join(PKG_DIR, "bin")
+INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
+
+ENGINE_SIMPLE, ENGINE_FUSED = 0, 1
+NSTATES = 1 << 23
+ROWBYTES = NSTATES // 8
+
+u8p = C.POINTER(C.c_uint8)
+
+# every symbol include/viterbi224.h and include/viterbi224_hip.h declare
+V224_SYMBOLS = [
+    "init_viterbi224", "create_viterbi224", "chainback_viterbi224", "delete_viterbi224",
+    "update_viterbi224_blk", "max_metric_viterbi224", "min_metric_viterbi224",
+    "decodebit_viterbi224", "decodeword_viterbi224",
+    "v224hip_device_count", "v224hip_set_device", "v224hip_create", "v224hip_last_error",
+    "v224hip_update_dev", "v224hip_stream_decode", "v224hip_stream_decode_dev",
+    "v224hip_stream_chunk", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
+    "v224hip_export_row", "v224hip_export_metrics", "v224hip_dev_alloc", "v224hip_dev_free",
+    "v224hip_h2d", "v224hip_d2h",
+]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path(name):
+    return os.path.join(LIB_DIR, name)
+
+
+_v224 = None
+
+
+def v224_lib():
+    """Load libviterbi224_hip.so (raises NativeLibraryMissing when it has not been built)."""
+    global _v224
+    if _v224 is not None:
+        return _v224
+    path = lib_path("libviterbi224_hip.so")
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    L.create_viterbi224.restype = C.c_void_p
+    L.create_viterbi224.argtypes = [C.c_int]
+    L.v224hip_create.restype = C.c_void_p
+    L.v224hip_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.v224hip_last_error.restype = C.c_char_p
+    L.init_viterbi224.argtypes = [C.c_void_p, C.c_int]
+    L.update_viterbi224_blk.argtypes = [C.c_void_p, u8p, C.c_int]
+    L.chainback_viterbi224.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_uint]
+    L.decodebit_viterbi224.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.decodeword_viterbi224.restype = C.c_ulonglong
+    L.decodeword_viterbi224.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.max_metric_viterbi224.argtypes = [C.c_void_p]
+    L.min_metric_viterbi224.argtypes = [C.c_void_p]
+    L.delete_viterbi224.argtypes = [C.c_void_p]
+    L.delete_viterbi224.restype = None
+    L.v224hip_set_device.argtypes = [C.c_int]
+    L.v224hip_update_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.v224hip_stream_decode.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p]
+    L.v224hip_stream_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.v224hip_stream_chunk.argtypes = [C.c_void_p]
+    L.v224hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    L.v224hip_sync.argtypes = [C.c_void_p]
+    L.v224hip_acs_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_ulonglong), C.c_int]
+    L.v224hip_export_row.argtypes = [C.c_void_p, C.c_int, u8p]
+    L.v224hip_export_metrics.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.v224hip_dev_alloc.restype = C.c_void_p
+    L.v224hip_dev_alloc.argtypes = [C.c_size_t]
+    L.v224hip_dev_free.argtypes = [C.c_void_p]
+    L.v224hip_dev_free.restype = None
+    L.v224hip_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.v224hip_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    _v224 = L
+    return L
+
+
+def last_error():
+    return (v224_lib().v224hip_last_error() or b"").decode()
+
+
+class DeviceBuffer:
+    """A chunk of HBM owned through the C-ABI (no torch types cross the boundary)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = v224_lib().v224hip_dev_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("v224hip_dev_alloc(%d) failed" % nbytes)
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        if v224_lib().v224hip_h2d(b.ptr, a.ctypes.data, a.nbytes) != 0:
+            raise RuntimeError("h2d failed")
+        return b
+
+    def to_numpy(self, dtype=np.uint8, count=None):
+        dt = np.dtype(dtype)
+        n = self.nbytes // dt.itemsize if count is None else count
+        out = np.empty(n, dtype=dt)
+        if v224_lib().v224hip_d2h(out.ctypes.data, self.ptr, out.nbytes) != 0:
+            raise RuntimeError("d2h failed")
+        return out
+
+    def free(self):
+        if self.ptr:
+            v224_lib().v224hip_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Viterbi224:
+    """Python mirror of the reference decoder API (viterbi224.h:8-16) on the HIP library.
+
+    Method names and argument meaning follow the C functions; errors raise instead of
+    returning -1/NULL.
+    """
+
+    def __init__(self, length, engine=-1, k=0):
+        L = v224_lib()
+        self.L = L
+        self.h = L.v224hip_create(int(length), int(engine), int(k))
+        if not self.h:
+            raise RuntimeError("create_viterbi224(%d) failed: %s" % (length, last_error()))
+        self.length = int(length)
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise RuntimeError("%s failed: %s" % (what, last_error()))
+        return rc
+
+    def init(self, starting_state=0):
+        return self._chk(self.L.init_viterbi224(self.h, int(starting_state)), "init_viterbi224")
+
+    def update(self, syms, nbits=None):
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        if nbits is None:
+            nbits = len(syms) // 2
+        if len(syms) < 2 * nbits:
+            raise ValueError("need 2*nbits symbols")
+        return self._chk(self.L.update_viterbi224_blk(self.h, syms.ctypes.data_as(u8p), int(nbits)),
+                         "update_viterbi224_blk")
+
+    def update_dev(self, dbuf, nbits, byte_offset=0):
+        return self._chk(self.L.v224hip_update_dev(self.h, dbuf.ptr + byte_offset, int(nbits)),
+                         "v224hip_update_dev")
+
+    def chainback(self, nbits, endstate=0):
+        out = np.zeros((nbits + 7) // 8, dtype=np.uint8)
+        self._chk(self.L.chainback_viterbi224(self.h, out.ctypes.data_as(u8p), int(nbits),
+                                              int(endstate) & 0xFFFFFFFF), "chainback_viterbi224")
+        return out
+
+    def decodebit(self, delay, endstate=0):
+        return self.L.decodebit_viterbi224(self.h, int(delay), int(endstate))
+
+    def decodeword(self, delay, endstate=0):
+        return int(self.L.decodeword_viterbi224(self.h, int(delay), int(endstate)))
+
+    def min_metric(self):
+        return self.L.min_metric_viterbi224(self.h)
+
+    def max_metric(self):
+        return self.L.max_metric_viterbi224(self.h)
+
+    def stream_decode(self, syms, delay=200, nbits=None):
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        if nbits is None:
+            nbits = len(syms) // 2
+        out = np.empty(nbits, dtype=np.uint8)
+        self._chk(self.L.v224hip_stream_decode(self.h, syms.ctypes.data_as(u8p), int(nbits), int(delay),
+                                               out.ctypes.data_as(u8p)), "v224hip_stream_decode")
+        return out
+
+    def stream_decode_dev(self, d_syms, nbits, delay, d_out, sym_offset=0, out_offset=0):
+        return self._chk(self.L.v224hip_stream_decode_dev(self.h, d_syms.ptr + sym_offset, int(nbits),
+                                                          int(delay), d_out.ptr + out_offset),
+                         "v224hip_stream_decode_dev")
+
+    def set_option(self, key, value):
+        return self._chk(self.L.v224hip_set_option(self.h, key.encode(), int(value)), "set_option " + key)
+
+    def stream_chunk(self):
+        return self.L.v224hip_stream_chunk(self.h)
+
+    def sync(self):
+        return self._chk(self.L.v224hip_sync(self.h), "v224hip_sync")
+
+    def acs_stats(self, reset=False):
+        n, ms, st = C.c_ulonglong(0), C.c_double(0), C.c_ulonglong(0)
+        self._chk(self.L.v224hip_acs_stats(self.h, C.byref(n), C.byref(ms), C.byref(st), int(reset)), "acs_stats")
+        return n.value, ms.value, st.value
+
+    def export_row(self, row):
+        out = np.empty(ROWBYTES, dtype=np.uint8)
+        self._chk(self.L.v224hip_export_row(self.h, int(row), out.ctypes.data_as(u8p)), "export_row")
+        return out
+
+    def export_metrics(self):
+        out = np.empty(NSTATES, dtype=np.uint32)
+        self._chk(self.L.v224hip_export_metrics(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32))), "export_metrics")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.delete_viterbi224(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,706 @@
+// v224_hip.hip -- K=24 r=1/2 Viterbi decoder for MI355X (gfx950): C-ABI + HIP kernels.
+//
+// Replaces viterbi224_port.c / viterbi224_sse2.c behind the reference's own API
+// (reference viterbi224.h:8-16; include/viterbi224.h here).  Semantics are the PORT's:
+//   ACS       port.c:159-195   tie -> predecessor with MSB set, metrics never saturate
+//   init      port.c:34-48     1000 everywhere, 0 at the start state
+//   chainback port.c:72-101    rows n % len, bytes MSB-first
+//   decodebit port.c:104-143   walk back from the newest row with ring wrap
+//
+// Data layout in HBM (per decoder):
+//   metrics   2 x 2^23 x u16 (16 MiB each, ping-pong).  16 bits suffice: the port's u32 metrics
+//             are only ever compared pairwise and their spread is < 12 731 + 510, so a common
+//             offset can be subtracted at will (struct V224Dev::off keeps the running total).
+//   decisions ring of `len` rows x 1 MiB; rowmeta[row] says in which bit order the row was
+//             written (port order by the simple engine, permuted by the fused engine).
+//   V224Dev   min slots + offset, updated by the kernels themselves (no host round trip).
+//
+// Engines:
+//   SIMPLE  one trellis step per launch.  Thread t owns butterflies 16t..16t+15: two 32-byte
+//           coalesced reads (old[i], old[i+2^22]), one 64-byte write (new[2i..2i+31]) and one
+//           decision dword in port order.  34.6 MB of HBM traffic per step.
+//   FUSED   see v224_fused.hip.inc: K steps per launch with the path metrics of 2^K states held
+//           in packed-u16 VGPRs, so metric traffic drops to 32 MiB / K per step.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "v224_common.h"
+#pragma GCC visibility push(default)
+#include "../../include/viterbi224_hip.h"
+#pragma GCC visibility pop
+
+// ------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void v224_set_error(const char *what, hipError_t e, const char *file, int line) {
+  snprintf(g_err, sizeof g_err, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+}
+extern "C" const char *v224hip_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// host object
+// ------------------------------------------------------------------------------------------
+struct EvPair { hipEvent_t a, b; unsigned steps; };
+
+struct V224 {
+  int len, engine, K, dev;
+  hipStream_t st;           // ACS stream
+  hipStream_t st2;          // traceback stream (stream_decode overlap)
+  uint16_t *m[2];
+  int cur;                  // index of the "old" metric buffer
+  uint32_t *rows;           // len x 2^18 dwords
+  uint32_t *rowmeta;        // len
+  V224Dev *ds;
+  uint8_t *dsyms; size_t dsyms_cap;
+  uint8_t *dout;  size_t dout_cap;
+  uint8_t *dmisc;           // small device scratch (chainback output etc.)
+  size_t dmisc_cap;
+  int dp;                   // next row to write
+  unsigned long long nsteps;// trellis steps since init
+  unsigned pass;            // ACS launches since init (slot rotation)
+  int chunk;                // stream chunk (bits)
+  int profile;              // sample every profile-th launch (0 = off)
+  unsigned long long launches_seen;
+  std::vector<EvPair> ev_busy, ev_free;
+  unsigned long long prof_launches, prof_steps; double prof_ms;
+  hipEvent_t ev_acs[2], ev_tb[2];
+};
+
+static int g_device = -1;
+
+extern "C" int v224hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+extern "C" int v224hip_set_device(int dev) {
+  if (hipSetDevice(dev) != hipSuccess) return -1;
+  g_device = dev;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels: init, simple ACS
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init(uint16_t *m, unsigned start, V224Dev *ds,
+                                              uint32_t *rowmeta, int len) {
+  unsigned t = blockIdx.x * 256 + threadIdx.x;            // 2^20 threads x 8 states
+  uint4 v;
+  const unsigned fill = (V224_BASE + 1000u) * 0x10001u;
+  v.x = v.y = v.z = v.w = fill;
+  reinterpret_cast<uint4 *>(m)[t] = v;
+  if (t == 0) {
+    ds->slot[0] = V224_BASE; ds->slot[1] = 0xffffffffu; ds->slot[2] = 0xffffffffu; ds->slot[3] = 0;
+    ds->off = -(long long)V224_BASE;
+  }
+  (void)rowmeta; (void)len;
+}
+__global__ void k_init_start(uint16_t *m, unsigned start) { m[start] = (uint16_t)V224_BASE; }
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+// parity of (2i & POLY1) for i = 0..15 as a 16-bit mask (bit n set => flip)
+__host__ __device__ constexpr unsigned par_low16() {
+  unsigned m = 0;
+  for (unsigned n = 0; n < 16; n++) {
+    unsigned x = (2 * n) & V224_POLY1, p = 0;
+    while (x) { p ^= x & 1; x >>= 1; }
+    m |= p << n;
+  }
+  return m;
+}
+
+// One trellis step, port bit order.  grid = 2^18 threads.
+__global__ __launch_bounds__(256) void k_acs_simple(const uint16_t *__restrict__ oldm,
+                                                    uint16_t *__restrict__ newm,
+                                                    uint32_t *__restrict__ row,
+                                                    const uint8_t *__restrict__ syms,
+                                                    V224Dev *ds, unsigned pass,
+                                                    uint32_t *rowmeta, int rowidx) {
+  const unsigned t = blockIdx.x * 256 + threadIdx.x;
+  const unsigned adj = ds->slot[pass % 3] - V224_BASE;   // wave-uniform scalar load
+  const unsigned s0 = syms[0], s1 = syms[1];
+  const unsigned c0 = s0 + 255 - s1, c1 = s0 + s1;
+
+  const uint4 *pi = reinterpret_cast<const uint4 *>(oldm + 16 * t);
+  const uint4 *pj = reinterpret_cast<const uint4 *>(oldm + V224_NBFLY + 16 * t);
+  uint4 vi[2] = { pi[0], pi[1] }, vj[2] = { pj[0], pj[1] };
+  const unsigned *wi = reinterpret_cast<const unsigned *>(vi);
+  const unsigned *wj = reinterpret_cast<const unsigned *>(vj);
+
+  // parity(2i & POLY1) for i = 16t+n splits into parity(32t & POLY1) ^ parity(2n & POLY1)
+  constexpr unsigned PLOW = par_low16();
+  const unsigned pbase = __popc((32u * t) & V224_POLY1) & 1u;
+  const unsigned pmask = pbase ? (~PLOW & 0xffffu) : PLOW;
+
+  unsigned outw[16];
+  unsigned dec = 0, mn = 0xffffffffu;
+#pragma unroll
+  for (int n = 0; n < 16; n++) {
+    unsigned oi = ((wi[n >> 1] >> (16 * (n & 1))) & 0xffffu) - adj;
+    unsigned oj = ((wj[n >> 1] >> (16 * (n & 1))) & 0xffffu) - adj;
+    unsigned c = (n & 1) ? c1 : c0;
+    unsigned bm = ((pmask >> n) & 1u) ? 510u - c : c;
+    unsigned a0 = oi + bm, a1 = oj + 510u - bm;      // into new state 2i
+    unsigned b0 = oi + 510u - bm, b1 = oj + bm;      // into new state 2i+1
+    unsigned d0 = a0 >= a1, d1 = b0 >= b1;           // tie -> MSB-set predecessor (port.c:178)
+    unsigned n0 = d0 ? a1 : a0, n1 = d1 ? b1 : b0;
+    dec |= (d0 | (d1 << 1)) << (2 * n);
+    outw[n] = n0 | (n1 << 16);
+    unsigned m2 = n0 < n1 ? n0 : n1;
+    mn = m2 < mn ? m2 : mn;
+  }
+  uint4 *po = reinterpret_cast<uint4 *>(newm + 32 * t);
+#pragma unroll
+  for (int q = 0; q < 4; q++) po[q] = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
+  row[t] = dec;
+
+  mn = wave_min_u32(mn);
+  __shared__ unsigned smin[4];
+  if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = smin[0] < smin[1] ? smin[0] : smin[1];
+    unsigned b = smin[2] < smin[3] ? smin[2] : smin[3];
+    atomicMin(&ds->slot[(pass + 1) % 3], a < b ? a : b);
+    if (blockIdx.x == 0) {
+      ds->slot[(pass + 2) % 3] = 0xffffffffu;       // read by launch pass-1, which has finished
+      ds->off += (long long)adj;
+      rowmeta[rowidx] = V224_META_PORT;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// decision-bit fetch (all layouts) and traceback kernels
+// ------------------------------------------------------------------------------------------
+#include "v224_fused.hip.inc"
+
+__device__ __forceinline__ unsigned get_decision(const uint32_t *__restrict__ rows,
+                                                 const uint32_t *__restrict__ rowmeta,
+                                                 int row, unsigned state) {
+  const uint32_t *r = rows + (size_t)row * V224_ROWWORDS;
+  unsigned meta = rowmeta[row];
+  if (meta == V224_META_PORT) return (r[state >> 5] >> (state & 31)) & 1u;
+  return fused_get_decision(r, meta, state);
+}
+
+// out[j] = decodebit(delay, endstate) as it would read right after trellis step (first + j);
+// dp_first = ring index of the row following that step's row.  0xff while history < delay.
+__global__ __launch_bounds__(64) void k_decodebits(const uint32_t *__restrict__ rows,
+                                                   const uint32_t *__restrict__ rowmeta, int len,
+                                                   int dp_first, unsigned long long steps_first,
+                                                   int n, int delay, unsigned endstate,
+                                                   uint8_t *__restrict__ out) {
+  int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= n) return;
+  if (steps_first + (unsigned long long)j < (unsigned long long)delay) { out[j] = 0xff; return; }
+  int row = (int)(((long long)dp_first + j) % len);
+  unsigned st = endstate & V224_SMASK, bit = 0;
+  for (int d = 0; d < delay; d++) {
+    if (--row < 0) row = len - 1;
+    bit = get_decision(rows, rowmeta, row, st);
+    st = (bit << (V224_K - 2)) | (st >> 1);
+  }
+  out[j] = (uint8_t)bit;
+}
+
+// framed chainback, port.c:86-98 (row = n % len).  One lane; the walk is a dependent chain.
+__global__ void k_chainback(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta,
+                            int len, unsigned nbits, unsigned endstate, uint8_t *__restrict__ data) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned st = endstate & V224_SMASK, acc = 0;
+  for (unsigned n = nbits; n-- > 0;) {
+    acc = ((st & 1u) << 7) | (acc >> 1);
+    if ((n & 7u) == 0) data[n >> 3] = (uint8_t)acc;
+    unsigned b = get_decision(rows, rowmeta, (int)(n % (unsigned)len), st);
+    st = (b << (V224_K - 2)) | (st >> 1);
+  }
+}
+
+// decodeword, sse2.c:206-243: result = bit<<63 | result>>1 per step
+__global__ void k_decodeword(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta,
+                             int len, int dp, int delay, unsigned endstate,
+                             unsigned long long *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned st = endstate & V224_SMASK;
+  unsigned long long r = 0;
+  int row = dp;
+  for (int d = 0; d < delay; d++) {
+    if (--row < 0) row = len - 1;
+    unsigned bit = get_decision(rows, rowmeta, row, st);
+    st = (bit << (V224_K - 2)) | (st >> 1);
+    r = ((unsigned long long)bit << 63) | (r >> 1);
+  }
+  *out = r;
+}
+
+// first index holding the minimum (port.c:113-122: strict <, lowest index wins).
+// minval = min of the current buffer, already known from the last ACS launch's slot.
+__global__ __launch_bounds__(256) void k_argmin(const uint16_t *__restrict__ m, const V224Dev *ds,
+                                                unsigned slot, unsigned *out) {
+  unsigned t = blockIdx.x * 256 + threadIdx.x;       // 2^20 threads x 8 states
+  unsigned minval = ds->slot[slot];
+  uint4 v = reinterpret_cast<const uint4 *>(m)[t];
+  const unsigned *w = reinterpret_cast<const unsigned *>(&v);
+  unsigned best = 0xffffffffu;
+#pragma unroll
+  for (int n = 7; n >= 0; n--) {
+    unsigned x = (w[n >> 1] >> (16 * (n & 1))) & 0xffffu;
+    if (x == minval) best = 8 * t + n;
+  }
+  best = wave_min_u32(best);
+  if ((threadIdx.x & 63) == 0 && best != 0xffffffffu) atomicMin(out, best);
+}
+
+__global__ __launch_bounds__(256) void k_max(const uint16_t *__restrict__ m, unsigned *out) {
+  unsigned t = blockIdx.x * 256 + threadIdx.x;
+  uint4 v = reinterpret_cast<const uint4 *>(m)[t];
+  const unsigned *w = reinterpret_cast<const unsigned *>(&v);
+  unsigned mx = 0;
+#pragma unroll
+  for (int n = 0; n < 8; n++) {
+    unsigned x = (w[n >> 1] >> (16 * (n & 1))) & 0xffffu;
+    mx = x > mx ? x : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { unsigned y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, mx);
+}
+
+// test export: any layout -> port bit order
+__global__ __launch_bounds__(256) void k_export_row(const uint32_t *__restrict__ rows,
+                                                    const uint32_t *__restrict__ rowmeta, int row,
+                                                    uint32_t *__restrict__ out) {
+  unsigned t = blockIdx.x * 256 + threadIdx.x;       // 2^18 words
+  unsigned w = 0;
+  for (unsigned b = 0; b < 32; b++) w |= get_decision(rows, rowmeta, row, 32 * t + b) << b;
+  out[t] = w;
+}
+
+__global__ __launch_bounds__(256) void k_export_metrics(const uint16_t *__restrict__ m,
+                                                        const V224Dev *ds, unsigned slot,
+                                                        uint32_t *__restrict__ out) {
+  unsigned t = blockIdx.x * 256 + threadIdx.x;       // 2^23 threads
+  out[t] = (unsigned)m[t] - ds->slot[slot];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+extern "C" void *v224hip_create(int len, int engine, int k) {
+  V224 *v = nullptr;
+  if (len <= 0) { snprintf(g_err, sizeof g_err, "create: len must be > 0"); return nullptr; }
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      snprintf(g_err, sizeof g_err, "create: no HIP device visible");
+      return nullptr;
+    }
+  }
+  v = new V224();
+  v->len = len;
+  v->engine = engine >= 0 ? engine : env_int("V224HIP_ENGINE", V224HIP_ENGINE_FUSED);
+  v->K = k > 0 ? k : env_int("V224HIP_K", FUSED_DEFAULT_K);
+  if (v->K < 1) v->K = 1;
+  if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;
+  v->dev = g_device >= 0 ? g_device : env_int("V224HIP_DEVICE", 0);
+  v->chunk = env_int("V224HIP_CHUNK", 1024);
+  HIPCHK(hipSetDevice(v->dev));
+  HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&v->m[0], sizeof(uint16_t) * V224_NSTATES));
+  HIPCHK(hipMalloc(&v->m[1], sizeof(uint16_t) * V224_NSTATES));
+  HIPCHK(hipMalloc(&v->rows, (size_t)len * V224_ROWWORDS * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&v->rowmeta, (size_t)len * sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(v->rowmeta, 0, (size_t)len * sizeof(uint32_t), v->st));
+  HIPCHK(hipMalloc(&v->ds, sizeof(V224Dev)));
+  v->dmisc_cap = 1 << 20;
+  HIPCHK(hipMalloc(&v->dmisc, v->dmisc_cap));
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipEventCreateWithFlags(&v->ev_acs[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&v->ev_tb[i], hipEventDisableTiming));
+  }
+  if (init_viterbi224(v, 0) != 0) goto fail;
+  return v;
+fail:
+  delete_viterbi224(v);
+  return nullptr;
+}
+
+extern "C" void *create_viterbi224(int len) { return v224hip_create(len, -1, 0); }
+
+extern "C" void delete_viterbi224(void *p) {
+  V224 *v = (V224 *)p;
+  if (!v) return;
+  (void)hipSetDevice(v->dev);
+  if (v->st) (void)hipStreamSynchronize(v->st);
+  if (v->st2) (void)hipStreamSynchronize(v->st2);
+  for (auto &e : v->ev_busy) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto &e : v->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (int i = 0; i < 2; i++) {
+    if (v->ev_acs[i]) (void)hipEventDestroy(v->ev_acs[i]);
+    if (v->ev_tb[i]) (void)hipEventDestroy(v->ev_tb[i]);
+  }
+  (void)hipFree(v->m[0]); (void)hipFree(v->m[1]); (void)hipFree(v->rows); (void)hipFree(v->rowmeta);
+  (void)hipFree(v->ds); (void)hipFree(v->dsyms); (void)hipFree(v->dout); (void)hipFree(v->dmisc);
+  if (v->st) (void)hipStreamDestroy(v->st);
+  if (v->st2) (void)hipStreamDestroy(v->st2);
+  delete v;
+}
+
+extern "C" int init_viterbi224(void *p, int starting_state) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  HIPCHK(hipSetDevice(v->dev));
+  HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
+  v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0;
+  k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
+  k_init_start<<<1, 1, 0, v->st>>>(v->m[0], (unsigned)starting_state & V224_SMASK);
+  HIPCHK(hipGetLastError());
+  return 0;
+fail:
+  return -1;
+}
+
+// ---- profiling helpers -------------------------------------------------------------------
+static void prof_harvest(V224 *v, bool all) {
+  size_t keep = 0;
+  for (size_t i = 0; i < v->ev_busy.size(); i++) {
+    EvPair &e = v->ev_busy[i];
+    bool done = all ? (hipEventSynchronize(e.b) == hipSuccess) : (hipEventQuery(e.b) == hipSuccess);
+    if (done) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+        v->prof_ms += ms; v->prof_launches++; v->prof_steps += e.steps;
+      }
+      v->ev_free.push_back(e);
+    } else v->ev_busy[keep++] = e;
+  }
+  v->ev_busy.resize(keep);
+}
+static bool prof_begin(V224 *v, EvPair *e, unsigned steps) {
+  if (!v->profile) return false;
+  if ((v->launches_seen++ % (unsigned)v->profile) != 0) return false;
+  if (v->ev_free.empty()) {
+    if (v->ev_busy.size() >= 2048) prof_harvest(v, false);
+    if (v->ev_free.empty()) {
+      if (v->ev_busy.size() >= 8192) prof_harvest(v, true);
+      else { EvPair n; n.steps = 0;
+             if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return false;
+             v->ev_free.push_back(n); }
+    }
+  }
+  *e = v->ev_free.back(); v->ev_free.pop_back();
+  e->steps = steps;
+  (void)hipEventRecord(e->a, v->st);
+  return true;
+}
+static void prof_end(V224 *v, EvPair *e) { (void)hipEventRecord(e->b, v->st); v->ev_busy.push_back(*e); }
+
+// ---- ACS dispatch --------------------------------------------------------------------------
+// Enqueue nbits trellis steps reading symbols from device memory (2 per step).
+static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
+  int done = 0;
+  while (done < nbits) {
+    int k = 1;
+    if (v->engine == V224HIP_ENGINE_FUSED) {
+      k = v->K;
+      if (k > nbits - done) k = nbits - done;
+      if (k > v->len - v->dp) k = v->len - v->dp;      // a pass never wraps the ring
+    }
+    EvPair ev; bool timed = prof_begin(v, &ev, (unsigned)k);
+    if (v->engine == V224HIP_ENGINE_FUSED) {
+      if (fused_launch(k, v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
+                       v->pass, v->rowmeta, v->st) != 0) {
+        snprintf(g_err, sizeof g_err, "fused_launch(k=%d) failed", k);
+        return -1;
+      }
+    } else {
+      k_acs_simple<<<V224_NSTATES / 32 / 256, 256, 0, v->st>>>(
+          v->m[v->cur], v->m[v->cur ^ 1], v->rows + (size_t)v->dp * V224_ROWWORDS,
+          d_syms + 2 * done, v->ds, v->pass, v->rowmeta, v->dp);
+    }
+    if (timed) prof_end(v, &ev);
+    v->cur ^= 1; v->pass++;
+    v->dp += k; if (v->dp >= v->len) v->dp = 0;
+    v->nsteps += (unsigned)k;
+    done += k;
+  }
+  if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof g_err, "ACS launch failed"); return -1; }
+  return 0;
+}
+
+static int ensure_cap(uint8_t **buf, size_t *cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr; *cap = 0;
+  size_t n = need < 4096 ? 4096 : need;
+  if (hipMalloc(buf, n) != hipSuccess) return -1;
+  *cap = n;
+  return 0;
+}
+
+extern "C" int update_viterbi224_blk(void *p, const unsigned char *syms, int nbits) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (nbits <= 0) return 0;
+  HIPCHK(hipSetDevice(v->dev));
+  // the previous H2D into dsyms may still be feeding queued launches: drain before reuse
+  HIPCHK(hipStreamSynchronize(v->st));
+  if (ensure_cap(&v->dsyms, &v->dsyms_cap, 2 * (size_t)nbits) != 0) {
+    snprintf(g_err, sizeof g_err, "update: device symbol buffer allocation failed");
+    return -1;
+  }
+  HIPCHK(hipMemcpyAsync(v->dsyms, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice, v->st));
+  if (enqueue_acs(v, v->dsyms, nbits) != 0) return -1;
+  return 0;                                          // port convention (port.c:194)
+fail:
+  return -1;
+}
+
+extern "C" int v224hip_update_dev(void *p, const uint8_t *d_syms, int nbits) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (nbits <= 0) return 0;
+  if (hipSetDevice(v->dev) != hipSuccess) return -1;
+  return enqueue_acs(v, d_syms, nbits);
+}
+
+static int best_state(V224 *v, unsigned *state) {
+  unsigned *d = (unsigned *)v->dmisc;
+  HIPCHK(hipMemsetAsync(d, 0xff, sizeof(unsigned), v->st));
+  k_argmin<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass % 3, d);
+  HIPCHK(hipMemcpyAsync(state, d, sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  return 0;
+fail:
+  return -1;
+}
+
+extern "C" int decodebit_viterbi224(void *p, int delay, int endstate) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (delay <= 0) return -1;                           // port.c:128-129: bit stays -1
+  uint8_t bit = 0;
+  unsigned st = (unsigned)endstate;
+  HIPCHK(hipSetDevice(v->dev));
+  if (endstate < 0 && best_state(v, &st) != 0) return -1;
+  // steps_first is forced large: like the port, read whatever the ring holds
+  k_decodebits<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, v->dp, 1ull << 40, 1, delay, st, v->dmisc + 64);
+  HIPCHK(hipMemcpyAsync(&bit, v->dmisc + 64, 1, hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  return bit;
+fail:
+  return -1;
+}
+
+extern "C" unsigned long long decodeword_viterbi224(void *p, int delay, int endstate) {
+  V224 *v = (V224 *)p;
+  unsigned long long r = 0;
+  unsigned st = (unsigned)endstate & 0xffffffu;        // sse2.c:228
+  if (!v) return 0;
+  HIPCHK(hipSetDevice(v->dev));
+  if (endstate < 0 && best_state(v, &st) != 0) return 0;
+  k_decodeword<<<1, 1, 0, v->st>>>(v->rows, v->rowmeta, v->len, v->dp, delay, st,
+                                   (unsigned long long *)(v->dmisc + 128));
+  HIPCHK(hipMemcpyAsync(&r, v->dmisc + 128, sizeof r, hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  return r;
+fail:
+  return 0;
+}
+
+extern "C" int chainback_viterbi224(void *p, unsigned char *data, unsigned int nbits,
+                                    unsigned int endstate) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (nbits == 0) return 0;
+  {
+    size_t nbytes = (nbits + 7) / 8;
+    HIPCHK(hipSetDevice(v->dev));
+    if (ensure_cap(&v->dout, &v->dout_cap, nbytes) != 0) return -1;
+    k_chainback<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, v->dout);
+    // the port writes data[n>>3] only where (n & 7) == 0, i.e. nbits/8 bytes (+1 if ragged)
+    HIPCHK(hipMemcpyAsync(data, v->dout, nbytes, hipMemcpyDeviceToHost, v->st));
+    HIPCHK(hipStreamSynchronize(v->st));
+  }
+  return 0;
+fail:
+  return -1;
+}
+
+static int metric_extreme(V224 *v, int want_max, long long *out) {
+  unsigned *d = (unsigned *)(v->dmisc + 256);
+  unsigned h[2]; long long off;
+  HIPCHK(hipSetDevice(v->dev));
+  HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned), v->st));
+  if (want_max) k_max<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], d);
+  HIPCHK(hipMemcpyAsync(&h[0], d, sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipMemcpyAsync(&h[1], &v->ds->slot[v->pass % 3], sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipMemcpyAsync(&off, &v->ds->off, sizeof off, hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  *out = (long long)(want_max ? h[0] : h[1]) + off;
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int max_metric_viterbi224(void *p) {
+  long long r;
+  if (!p || metric_extreme((V224 *)p, 1, &r) != 0) return -1;
+  return (int)r;
+}
+extern "C" int min_metric_viterbi224(void *p) {
+  long long r;
+  if (!p || metric_extreme((V224 *)p, 0, &r) != 0) return -1;
+  return (int)r;
+}
+
+// ---- streaming block decode -------------------------------------------------------------
+extern "C" int v224hip_stream_chunk(void *p) { return p ? ((V224 *)p)->chunk : -1; }
+
+// ACS of chunk c runs on st; its tracebacks run on st2 while chunk c+1's ACS proceeds.
+// Ring safety: chunk c+2's ACS (which may overwrite rows chunk c's traceback still reads once
+// len < delay + 3*chunk) waits for chunk c's traceback event.
+extern "C" int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbits, int delay,
+                                         uint8_t *d_out) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (nbits <= 0) return 0;
+  if (delay <= 0 || v->len < delay + 2 * v->chunk) {
+    snprintf(g_err, sizeof g_err, "stream_decode: need len >= delay + 2*chunk (len=%d delay=%d chunk=%d)",
+             v->len, delay, v->chunk);
+    return -1;
+  }
+  HIPCHK(hipSetDevice(v->dev));
+  {
+    int c = 0;
+    for (int done = 0; done < nbits; c++) {
+      int n = nbits - done < v->chunk ? nbits - done : v->chunk;
+      if (c >= 2) HIPCHK(hipStreamWaitEvent(v->st, v->ev_tb[c & 1], 0));
+      int dp_first = (v->dp + 1) % v->len;            // ring index after the chunk's first step
+      unsigned long long steps_first = v->nsteps + 1;
+      if (enqueue_acs(v, d_syms + 2 * (size_t)done, n) != 0) return -1;
+      HIPCHK(hipEventRecord(v->ev_acs[c & 1], v->st));
+      HIPCHK(hipStreamWaitEvent(v->st2, v->ev_acs[c & 1], 0));
+      k_decodebits<<<(n + 63) / 64, 64, 0, v->st2>>>(v->rows, v->rowmeta, v->len, dp_first, steps_first,
+                                                    n, delay, 0u, d_out + done);
+      HIPCHK(hipEventRecord(v->ev_tb[c & 1], v->st2));
+      done += n;
+    }
+    HIPCHK(hipGetLastError());
+    // leave st ordered after the last tracebacks so that later API calls see a quiet ring
+    HIPCHK(hipStreamWaitEvent(v->st, v->ev_tb[(c - 1) & 1], 0));
+    if (c >= 2) HIPCHK(hipStreamWaitEvent(v->st, v->ev_tb[c & 1], 0));
+  }
+  return 0;
+fail:
+  return -1;
+}
+
+extern "C" int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, uint8_t *out) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (nbits <= 0) return 0;
+  HIPCHK(hipSetDevice(v->dev));
+  HIPCHK(hipStreamSynchronize(v->st));
+  if (ensure_cap(&v->dsyms, &v->dsyms_cap, 2 * (size_t)nbits) != 0) return -1;
+  if (ensure_cap(&v->dout, &v->dout_cap, (size_t)nbits) != 0) return -1;
+  HIPCHK(hipMemcpyAsync(v->dsyms, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice, v->st));
+  if (v224hip_stream_decode_dev(p, v->dsyms, nbits, delay, v->dout) != 0) return -1;
+  HIPCHK(hipMemcpyAsync(out, v->dout, (size_t)nbits, hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  return 0;
+fail:
+  return -1;
+}
+
+extern "C" int v224hip_set_option(void *p, const char *key, long value) {
+  V224 *v = (V224 *)p;
+  if (!v || !key) return -1;
+  if (!strcmp(key, "chunk")) { if (value < 1) return -1; v->chunk = (int)value; return 0; }
+  if (!strcmp(key, "profile")) { if (value < 0) return -1; v->profile = (int)value; return 0; }
+  return -1;
+}
+
+extern "C" int v224hip_sync(void *p) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  if (hipSetDevice(v->dev) != hipSuccess) return -1;
+  if (hipStreamSynchronize(v->st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(v->st2) != hipSuccess) return -1;
+  return 0;
+}
+
+extern "C" int v224hip_acs_stats(void *p, unsigned long long *launches, double *total_ms,
+                                 unsigned long long *steps, int reset) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  prof_harvest(v, true);
+  if (launches) *launches = v->prof_launches;
+  if (total_ms) *total_ms = v->prof_ms;
+  if (steps) *steps = v->prof_steps;
+  if (reset) { v->prof_launches = 0; v->prof_ms = 0; v->prof_steps = 0; }
+  return 0;
+}
+
+extern "C" int v224hip_export_row(void *p, int row, uint8_t *out) {
+  V224 *v = (V224 *)p;
+  uint32_t *d = nullptr;
+  if (!v || row < 0 || row >= v->len) return -1;
+  HIPCHK(hipSetDevice(v->dev));
+  HIPCHK(hipMalloc(&d, V224_ROWWORDS * sizeof(uint32_t)));
+  k_export_row<<<V224_ROWWORDS / 256, 256, 0, v->st>>>(v->rows, v->rowmeta, row, d);
+  HIPCHK(hipMemcpyAsync(out, d, V224_ROWWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  (void)hipFree(d);
+  return 0;
+fail:
+  if (d) (void)hipFree(d);
+  return -1;
+}
+
+extern "C" int v224hip_export_metrics(void *p, uint32_t *out) {
+  V224 *v = (V224 *)p;
+  uint32_t *d = nullptr;
+  if (!v) return -1;
+  HIPCHK(hipSetDevice(v->dev));
+  HIPCHK(hipMalloc(&d, (size_t)V224_NSTATES * sizeof(uint32_t)));
+  k_export_metrics<<<V224_NSTATES / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass % 3, d);
+  HIPCHK(hipMemcpyAsync(out, d, (size_t)V224_NSTATES * sizeof(uint32_t), hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  (void)hipFree(d);
+  return 0;
+fail:
+  if (d) (void)hipFree(d);
+  return -1;
+}
+
+extern "C" void *v224hip_dev_alloc(size_t bytes) {
+  void *d = nullptr;
+  if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return d;
+}
+extern "C" void v224hip_dev_free(void *d) { if (d) (void)hipFree(d); }
+extern "C" int v224hip_h2d(void *d, const void *h, size_t n) {
+  return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+extern "C" int v224hip_d2h(void *h, const void *d, size_t n) {
+  return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}

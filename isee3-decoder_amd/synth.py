@@ -1,0 +1,45 @@
+"""Synthetic inputs for bench.py and the CLI demos (numpy only; independent of oracle/).
+
+Code constants: reference code.h:54-63 (MCQLI24: POLY1 = 073665667, POLY2 = 073665665, K = 24,
+second symbol inverted).  Encoder semantics: reference encode.c:17-35 (shift left, MSB-first data,
+symbol 0 from POLY1, symbol 1 from POLY2)."""
+import numpy as np
+
+POLY1 = 0o73665667
+POLY2 = 0o73665665
+K = 24
+
+
+def encode_bits(bits):
+    """bits: uint8 0/1 array -> interleaved hard symbols (2 per bit), encoder starting at state 0."""
+    bits = np.asarray(bits, dtype=np.uint8)
+    n = len(bits)
+    pad = np.concatenate([np.zeros(K - 1, np.uint8), bits])
+    y = []
+    for poly, flip in ((POLY1, 0), (POLY2, 1)):
+        acc = np.full(n, flip, dtype=np.uint8)
+        for k in range(K):
+            if (poly >> k) & 1:                   # tap k looks k bits into the past
+                acc ^= pad[K - 1 - k: K - 1 - k + n]
+        y.append(acc)
+    out = np.empty(2 * n, dtype=np.uint8)
+    out[0::2], out[1::2] = y[0], y[1]
+    return out
+
+
+def coded_stream(seed, nbits, ebn0_db=3.0, amplitude=24.0, noise_block_pct=1.0):
+    """8-bit offset-128 soft symbols of a continuously encoded random bit stream through AWGN
+    (noise level as reference vtest224.c:93-95); `noise_block_pct` % of 1024-symbol blocks are
+    replaced by pure noise.  Returns (symbols uint8[2*nbits], bits uint8[nbits])."""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, nbits, dtype=np.uint8)
+    hard = encode_bits(bits).astype(np.float32)
+    esn0 = ebn0_db + 10 * np.log10(0.5)
+    sigma = amplitude * np.sqrt(0.5) / 10 ** (0.05 * esn0)
+    sig = amplitude * (2 * hard - 1)
+    nblk = (2 * nbits + 1023) // 1024
+    noisy = rng.random(nblk) < noise_block_pct / 100.0
+    mask = np.repeat(noisy, 1024)[: 2 * nbits]
+    sig[mask] = 0
+    x = 128 + sig + rng.normal(0, sigma, 2 * nbits).astype(np.float32)
+    return np.clip(np.rint(x), 0, 255).astype(np.uint8), bits, mask

