@@ -40,6 +40,8 @@ def lib():
         so = os.path.join(ORACLE_DIR, "liboracle.so")
         if not os.path.exists(so):
             build_oracle()
+        # the GPU box exposes far more hardware threads than its CPU share: cap OpenMP
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
         L = C.CDLL(so)
         L.orc_v224_create.restype = C.c_void_p
         L.orc_v224_create.argtypes = [C.c_int, C.c_int]
