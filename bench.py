@@ -123,7 +123,7 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    dec.set_option("profile", 8)
+    dec.set_option("profile", 4)
     dec.acs_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -163,7 +163,7 @@ def main():
             "config": {"workload": "viterbi224 ACS+chainback streaming, 2^23 states, 8-bit soft syms, "
                                    "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
                        "engine": "fused" if dec.L.v224hip_stream_chunk(dec.h) and a.engine != 0 else "simple",
-                       "k": a.k or int(os.environ.get("V224HIP_K", "6")), "chunk_bits": chunk,
+                       "k": a.k or int(os.environ.get("V224HIP_K", "5")), "chunk_bits": chunk,
                        "segments_per_gpu": 1, "parallelism": "segments x%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,

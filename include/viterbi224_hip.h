@@ -42,15 +42,17 @@ int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, ui
 int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbits, int delay, uint8_t *d_out);
 int v224hip_stream_chunk(void *p);                 /* bits per internal chunk (option "chunk") */
 
-/* Generic option setter: "chunk" (bits per stream chunk), "profile" (1: time every ACS launch
- * with HIP events on the decoder's stream).  -1 on unknown key / bad value. */
+/* Generic option setter: "chunk" (bits per stream chunk), "profile" (N > 0: bracket every Nth run of back-to-back
+ * ACS launches -- one stream chunk or one update call -- with a HIP event pair on the decoder's
+ * stream).  -1 on unknown key / bad value. */
 int v224hip_set_option(void *p, const char *key, long value);
 
 /* Block until all enqueued work of this decoder has finished. */
 int v224hip_sync(void *p);
 
-/* ACS launch statistics since the last reset (needs option "profile"=1): number of ACS launches,
- * their summed device time in ms (hipEventElapsedTime per launch), trellis steps they covered. */
+/* ACS launch statistics since the last reset (needs option "profile" > 0): number of ACS launches
+ * inside the timed runs, the summed device time of those runs in ms (hipEventElapsedTime), and the
+ * trellis steps they covered. */
 int v224hip_acs_stats(void *p, unsigned long long *launches, double *total_ms,
                       unsigned long long *steps, int reset);
 

@@ -44,7 +44,7 @@ extern "C" const char *v224hip_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------
 // host object
 // ------------------------------------------------------------------------------------------
-struct EvPair { hipEvent_t a, b; unsigned steps; };
+struct EvPair { hipEvent_t a, b; unsigned steps, launches; };
 
 struct V224 {
   int len, engine, K, dev;
@@ -63,7 +63,7 @@ struct V224 {
   unsigned long long nsteps;// trellis steps since init
   unsigned pass;            // ACS launches since init (slot rotation)
   int chunk;                // stream chunk (bits)
-  int profile;              // sample every profile-th launch (0 = off)
+  int profile;              // time every profile-th run of ACS launches (0 = off)
   unsigned long long launches_seen;
   std::vector<EvPair> ev_busy, ev_free;
   unsigned long long prof_launches, prof_steps; double prof_ms;
@@ -388,14 +388,14 @@ static void prof_harvest(V224 *v, bool all) {
     if (done) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-        v->prof_ms += ms; v->prof_launches++; v->prof_steps += e.steps;
+        v->prof_ms += ms; v->prof_launches += e.launches; v->prof_steps += e.steps;
       }
       v->ev_free.push_back(e);
     } else v->ev_busy[keep++] = e;
   }
   v->ev_busy.resize(keep);
 }
-static bool prof_begin(V224 *v, EvPair *e, unsigned steps) {
+static bool prof_begin(V224 *v, EvPair *e) {
   if (!v->profile) return false;
   if ((v->launches_seen++ % (unsigned)v->profile) != 0) return false;
   if (v->ev_free.empty()) {
@@ -408,16 +408,23 @@ static bool prof_begin(V224 *v, EvPair *e, unsigned steps) {
     }
   }
   *e = v->ev_free.back(); v->ev_free.pop_back();
-  e->steps = steps;
   (void)hipEventRecord(e->a, v->st);
   return true;
 }
-static void prof_end(V224 *v, EvPair *e) { (void)hipEventRecord(e->b, v->st); v->ev_busy.push_back(*e); }
+static void prof_end(V224 *v, EvPair *e, unsigned steps, unsigned launches) {
+  e->steps = steps; e->launches = launches;
+  (void)hipEventRecord(e->b, v->st);
+  v->ev_busy.push_back(*e);
+}
 
 // ---- ACS dispatch --------------------------------------------------------------------------
 // Enqueue nbits trellis steps reading symbols from device memory (2 per step).
 static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
   int done = 0;
+  unsigned nlaunch = 0;
+  // profiling brackets the whole run of back-to-back launches with ONE event pair (an event
+  // pair around every single launch inflates it by ~3 us of signal handling)
+  EvPair ev; const bool timed = prof_begin(v, &ev);
   while (done < nbits) {
     int k = 1;
     if (v->engine == V224HIP_ENGINE_FUSED) {
@@ -425,7 +432,6 @@ static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
       if (k > nbits - done) k = nbits - done;
       if (k > v->len - v->dp) k = v->len - v->dp;      // a pass never wraps the ring
     }
-    EvPair ev; bool timed = prof_begin(v, &ev, (unsigned)k);
     if (v->engine == V224HIP_ENGINE_FUSED) {
       if (fused_launch(k, v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
                        v->pass, v->rowmeta, v->st) != 0) {
@@ -437,12 +443,13 @@ static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
           v->m[v->cur], v->m[v->cur ^ 1], v->rows + (size_t)v->dp * V224_ROWWORDS,
           d_syms + 2 * done, v->ds, v->pass, v->rowmeta, v->dp);
     }
-    if (timed) prof_end(v, &ev);
+    nlaunch++;
     v->cur ^= 1; v->pass++;
     v->dp += k; if (v->dp >= v->len) v->dp = 0;
     v->nsteps += (unsigned)k;
     done += k;
   }
+  if (timed) prof_end(v, &ev, (unsigned)nbits, nlaunch);
   if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof g_err, "ACS launch failed"); return -1; }
   return 0;
 }
