@@ -1,0 +1,87 @@
+/* isee3_dsp_hip.h -- C-ABI of libisee3dsp_hip.so: the data-parallel kernels of the pmdemod and
+ * symdemod pipe stages on MI355X (gfx950).
+ *
+ * The reference keeps these computations inline in two main() functions (pmdemod.c:204-368,
+ * symdemod.c:202-335); there is no library interface to mirror, so the boundary is drawn where the
+ * reference's own loops are: one call per loop nest, sequential control (buffer sliding, the
+ * scount += halfclock recurrences, Quinn interpolation, lock state) stays in the C host stages
+ * (isee3-decoder_amd/cli/{pmdemod,symdemod}_core.c).  Plain pointers and sizes only.
+ *
+ * All functions return 0 on success, -1 on error (isee3dsp_last_error() says why).
+ */
+#ifndef ISEE3_DSP_HIP_H
+#define ISEE3_DSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *isee3dsp_last_error(void);
+int isee3dsp_set_device(int dev);
+
+/* ------------------------------------------------------------------ symdemod (symdemod.c) ---- */
+/* One handle owns: a device copy of the current sample window and its exact int64 prefix sum. */
+void *symd_create(int max_samples);
+void  symd_destroy(void *h);
+
+/* Load n int16 samples (host pointer, or device pointer with is_dev = 1) and build
+ * P[k] = sum(samples[0..k)) in int64.  Every integrate-and-dump sum of symdemod.c:227-235 /
+ * :283-293 is then a difference of two P entries -- identical integers. */
+int symd_load(void *h, const int16_t *samples, int n, int is_dev);
+
+/* timesearch (symdemod.c:260-335) for offsets t = 0..noff-1 counted from base sample `lo`:
+ *   sw[0] = 0, sw[k+1] = reference switchpoints[k]  (2*symbolclocks*nsymbols + 1 entries, host)
+ *   energies[t] = sum over symbols, IN SYMBOL ORDER in double, of (long long)sym*sym
+ * The host picks the first maximum (strict '>', symdemod.c:327). */
+int symd_timesearch(void *h, int lo, const int *sw, int symbolclocks, int nsymbols, int noff,
+                    double *energies);
+
+/* trial_demod (symdemod.c:202-256).  edges[0] = first sample index, edges[k] the successive
+ * nearbyint(scount) boundaries (2*symbolclocks*nsymbols + 1 entries, host, indices into the
+ * loaded window).  energy_sum (may be NULL) = sequential double sum of sym^2;
+ * out (may be NULL; host, or device when out_is_dev) gets the 8-bit symbols when gain != 0:
+ * (unsigned char)clip(gain*integrator + 128, 0, 255)  (symdemod.c:240-251). */
+int symd_demod(void *h, const int *edges, int symbolclocks, int nsymbols, double gain,
+               uint8_t *out, int out_is_dev, double *energy_sum);
+
+/* ------------------------------------------------------------------ pmdemod (pmdemod.c) ------ */
+typedef struct {
+  int    peak;            /* argmax |X|^2 over [firstbin,lastbin), last maximum wins (pmdemod.c:288-298) */
+  double maxenergy;
+  double peak_re, peak_im, next_re, next_im, prev_re, prev_im;   /* bins for Quinn-2 (:299-318) */
+} pmd_peak;
+
+typedef struct {
+  double dc_re, dc_im;    /* mean of the spun-down block (pmdemod.c:332-336) */
+  double amplitude;       /* |dc| */
+  double diffsumsq;       /* mean((Re - amplitude)^2) after rotation (:341-348) */
+} pmd_mix;
+
+void *pmd_create(int fftsize);          /* fftsize = 2^n, 2^4 .. 2^24 */
+void  pmd_destroy(void *h);
+
+/* De-chirp LO (pmdemod.c:232-244): lophase_ri = fftsize complex doubles holding the reference's
+ * lophase sequence, produced on the host by that same sequential recurrence (it restarts every
+ * block, so it is computed once); its rounding walk (~i^1.5 * 1e-16) cannot be reproduced by a
+ * closed form.  NULL = off. */
+int pmd_set_dechirp(void *h, const double *lophase_ri);
+/* pmdemod.c:204-230 (+ :237 with a de-chirp table): int16 (I,Q) pairs -> double complex block;
+ * flip swaps I and Q.  iq is a host pointer, or a device pointer when is_dev. */
+int pmd_load(void *h, const int16_t *iq, int is_dev, int flip);
+/* pmdemod.c:253-298: forward unnormalised FFT (input preserved) + windowed peak search */
+int pmd_fft_peak(void *h, int firstbin, int lastbin, pmd_peak *out);
+/* pmdemod.c:321-368: spin down by cstep_rad = 2*pi*carrier_freq/samprate per sample (the closed
+ * form of the reference's carrier recurrence, csrc/carrier_params.c), average,
+ * rotate carrier onto the real axis, noise variance, quantise Im * sqrt(1/2) to int16.
+ * out16 / pre (optional pre-quantisation doubles) are host pointers, or device if out_is_dev. */
+int pmd_mix_quantise(void *h, double cstep_rad, pmd_mix *res, int16_t *out16, double *pre, int out_is_dev);
+/* test hook: copy the spectrum (fftsize complex doubles) to host */
+int pmd_get_spectrum(void *h, double *out_ri);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

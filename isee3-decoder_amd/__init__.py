@@ -237,3 +237,165 @@ class Viterbi224:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------------
+# libisee3dsp_hip.so : pmdemod / symdemod kernels (include/isee3_dsp_hip.h)
+# ------------------------------------------------------------------------------------------------
+DSP_SYMBOLS = [
+    "isee3dsp_last_error", "isee3dsp_set_device",
+    "symd_create", "symd_destroy", "symd_load", "symd_timesearch", "symd_demod",
+    "pmd_create", "pmd_destroy", "pmd_set_dechirp", "pmd_load", "pmd_fft_peak", "pmd_mix_quantise",
+    "pmd_get_spectrum",
+]
+
+
+class PmdPeak(C.Structure):
+    _fields_ = [("peak", C.c_int), ("maxenergy", C.c_double), ("peak_re", C.c_double), ("peak_im", C.c_double),
+                ("next_re", C.c_double), ("next_im", C.c_double), ("prev_re", C.c_double), ("prev_im", C.c_double)]
+
+
+class PmdMix(C.Structure):
+    _fields_ = [("dc_re", C.c_double), ("dc_im", C.c_double), ("amplitude", C.c_double), ("diffsumsq", C.c_double)]
+
+
+_dsp = None
+
+
+def dsp_lib():
+    global _dsp
+    if _dsp is not None:
+        return _dsp
+    path = lib_path("libisee3dsp_hip.so")
+    if not os.path.exists(path):
+        raise NativeLibraryMissing("%s not built (no CPU fallback)" % path)
+    L = C.CDLL(path)
+    L.isee3dsp_last_error.restype = C.c_char_p
+    L.isee3dsp_set_device.argtypes = [C.c_int]
+    L.symd_create.restype = C.c_void_p
+    L.symd_create.argtypes = [C.c_int]
+    L.symd_destroy.argtypes = [C.c_void_p]
+    L.symd_destroy.restype = None
+    L.symd_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.symd_timesearch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_double)]
+    L.symd_demod.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                             C.POINTER(C.c_double)]
+    L.pmd_create.restype = C.c_void_p
+    L.pmd_create.argtypes = [C.c_int]
+    L.pmd_destroy.argtypes = [C.c_void_p]
+    L.pmd_destroy.restype = None
+    L.pmd_set_dechirp.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmd_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.pmd_fft_peak.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(PmdPeak)]
+    L.pmd_mix_quantise.argtypes = [C.c_void_p, C.c_double, C.POINTER(PmdMix), C.c_void_p, C.c_void_p, C.c_int]
+    L.pmd_get_spectrum.argtypes = [C.c_void_p, C.c_void_p]
+    _dsp = L
+    return L
+
+
+def dsp_error():
+    return (dsp_lib().isee3dsp_last_error() or b"").decode()
+
+
+class SymDemodEngine:
+    """symd_* primitives (symdemod.c loop nests) on the GPU."""
+
+    def __init__(self, max_samples):
+        self.L = dsp_lib()
+        self.h = self.L.symd_create(int(max_samples))
+        if not self.h:
+            raise RuntimeError("symd_create failed: " + dsp_error())
+
+    def load(self, samples):
+        s = np.ascontiguousarray(samples, dtype=np.int16)
+        if self.L.symd_load(self.h, s.ctypes.data, len(s), 0) != 0:
+            raise RuntimeError("symd_load: " + dsp_error())
+
+    def timesearch(self, lo, sw, symbolclocks, nsymbols, noff):
+        sw = np.ascontiguousarray(sw, dtype=np.int32)
+        en = np.zeros(noff, dtype=np.float64)
+        if self.L.symd_timesearch(self.h, int(lo), sw.ctypes.data_as(C.POINTER(C.c_int)), symbolclocks, nsymbols,
+                                  noff, en.ctypes.data_as(C.POINTER(C.c_double))) != 0:
+            raise RuntimeError("symd_timesearch: " + dsp_error())
+        return en
+
+    def demod(self, edges, symbolclocks, nsymbols, gain):
+        edges = np.ascontiguousarray(edges, dtype=np.int32)
+        out = np.zeros(nsymbols, dtype=np.uint8)
+        e = C.c_double(0)
+        if self.L.symd_demod(self.h, edges.ctypes.data_as(C.POINTER(C.c_int)), symbolclocks, nsymbols, gain,
+                             out.ctypes.data, 0, C.byref(e)) != 0:
+            raise RuntimeError("symd_demod: " + dsp_error())
+        return out, e.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.symd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PmDemodEngine:
+    """pmd_* primitives (pmdemod.c per-sample loops) on the GPU."""
+
+    def __init__(self, fftsize):
+        self.L = dsp_lib()
+        self.N = int(fftsize)
+        self.h = self.L.pmd_create(self.N)
+        if not self.h:
+            raise RuntimeError("pmd_create failed: " + dsp_error())
+
+    def set_dechirp(self, table):
+        t = None if table is None else np.ascontiguousarray(table, dtype=np.complex128)
+        if self.L.pmd_set_dechirp(self.h, None if t is None else t.ctypes.data) != 0:
+            raise RuntimeError("pmd_set_dechirp: " + dsp_error())
+
+    def load(self, iq_block, flip=False):
+        iq = np.ascontiguousarray(iq_block, dtype=np.int16)
+        assert len(iq) == 2 * self.N
+        if self.L.pmd_load(self.h, iq.ctypes.data, 0, int(flip)) != 0:
+            raise RuntimeError("pmd_load: " + dsp_error())
+
+    def fft_peak(self, firstbin=0, lastbin=None):
+        pk = PmdPeak()
+        if self.L.pmd_fft_peak(self.h, firstbin, self.N if lastbin is None else lastbin, C.byref(pk)) != 0:
+            raise RuntimeError("pmd_fft_peak: " + dsp_error())
+        return pk
+
+    def spectrum(self):
+        out = np.zeros(self.N, dtype=np.complex128)
+        if self.L.pmd_get_spectrum(self.h, out.ctypes.data) != 0:
+            raise RuntimeError("pmd_get_spectrum: " + dsp_error())
+        return out
+
+    def mix_quantise(self, cstep):
+        mx = PmdMix()
+        out16 = np.zeros(self.N, dtype=np.int16)
+        pre = np.zeros(self.N, dtype=np.float64)
+        if self.L.pmd_mix_quantise(self.h, cstep, C.byref(mx), out16.ctypes.data, pre.ctypes.data, 0) != 0:
+            raise RuntimeError("pmd_mix_quantise: " + dsp_error())
+        return mx, out16, pre
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pmd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cli_path(name):
+    p = os.path.join(BIN_DIR, name)
+    if not os.path.exists(p):
+        raise NativeLibraryMissing("%s not built" % p)
+    return p

@@ -1,0 +1,154 @@
+/* pmdemod_core.c -- see pmdemod_core.h.  Plain C11 (build with -ffp-contract=off). */
+#define _GNU_SOURCE
+#include "pmdemod_core.h"
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include "timefmt.h"
+
+void pmdemod_default_opts(pmdemod_opts *o) {
+  memset(o, 0, sizeof *o);
+  o->samprate = 250000; o->binsize = 4; o->cn0_threshold = 21;   /* pmdemod.c:76-83 */
+  o->argv0 = "pmdemod";
+}
+
+int pmdemod_parse_args(pmdemod_opts *o, int argc, char **argv, FILE *err) {
+  int c;
+  pmdemod_default_opts(o);
+  if (argc > 0) o->argv0 = argv[0];
+  optind = 1; opterr = 0;
+  while ((c = getopt(argc, argv, "S:W:D:r:fb:qt:")) != -1) {
+    switch (c) {
+    case 'S': o->search_freq = atof(optarg); break;
+    case 'W': o->search_width = atof(optarg); break;
+    case 'D': o->doppler_rate = atof(optarg); break;
+    case 't': o->cn0_threshold = atof(optarg); break;
+    case 'q': o->quiet = 1; break;
+    case 'b': o->binsize = atof(optarg); break;
+    case 'r': o->samprate = atof(optarg); break;
+    case 'f': o->flip++; break;
+    default:
+      fprintf(err, "%s: unknown option %c\n", o->argv0, c);
+      return 1;                                      /* pmdemod.c:111-113 */
+    }
+  }
+  if (argc > optind) o->file = argv[optind];
+  return 0;
+}
+
+static double tau(double x) {                        /* Quinn's second estimator, pmdemod.c:43-46 */
+  return 0.25 * log(3 * x * x + 6 * x + 1)
+       - sqrt(6.) / 24 * log((x + 1 - sqrt(2 / 3.)) / (x + 1 + sqrt(2 / 3.)));
+}
+
+int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *out, FILE *err,
+                pmdemod_block_report *report, int report_cap, int *nreport) {
+  double Samprate = o->samprate, Search_width = o->search_width, Carrier_search_freq = o->search_freq;
+  double cn0 = -999;
+  int exitcode = 0, nb = 0;
+  void *h = NULL;
+  int16_t *iq = NULL, *out16 = NULL;
+  double *lo = NULL;
+  long long total_samples = 0;
+
+  if (nreport) *nreport = 0;
+  if (fabs(Carrier_search_freq) > Samprate / 2) {
+    fprintf(err, "%s: Carrier frequency of %'.1lf Hz is outside Nyquist bandwidth at %'.1lf Hz sample rate. Must be between +/- %'.1lf Hz\n",
+            o->argv0, Carrier_search_freq, Samprate, Samprate / 2);
+    return 1;
+  }
+  if (Search_width < 0) Search_width = fabs(Search_width);
+  if (Search_width > Samprate / 2) {
+    fprintf(err, "%s: Search width > 1/2 Nyquist rate; reduced to +/- %'.1lf Hz\n", o->argv0, Samprate / 2);
+    Search_width = Samprate / 2;
+  }
+  int lfftsize = (int)nearbyint(log2(Samprate / o->binsize));
+  int N = 1 << lfftsize;
+  double Binsize = Samprate / N;
+  if (!o->quiet)
+    fprintf(err, "%s: FFT bin size %'.4lf Hz; Start carrier %'.4lf Hz; Doppler %'.6lf Hz/s; Search range +/-%'.1lf Hz\n",
+            o->argv0, Samprate / N, Carrier_search_freq, o->doppler_rate, Search_width);
+  if (o->flip && !o->quiet) fprintf(err, "%s: I & Q samples swapped (spectrum inverted)\n", o->argv0);
+
+  h = e->create(N);
+  iq = malloc(sizeof(int16_t) * 2 * (size_t)N);
+  out16 = malloc(sizeof(int16_t) * (size_t)N);
+  if (!h || !iq || !out16) {
+    fprintf(err, "%s: cannot set up a %d-point FFT\n", o->argv0, N);
+    exitcode = 2;
+    goto done;
+  }
+  if (o->doppler_rate != 0) {
+    /* pmdemod.c:140-145,232-244: the LO restarts every block, so its phase sequence is a fixed
+       table; it is produced with the reference's own sequential recurrence (its rounding walk is
+       what the reference computes) and handed to the engine once */
+    double drate = o->doppler_rate * 2 * M_PI / (Samprate * Samprate);
+    double complex loaccel = cos(drate) + _Complex_I * sin(drate);
+    double complex lofreq = 1, lophase = 1;
+    lo = malloc(sizeof(double) * 2 * (size_t)N);
+    if (!lo) { exitcode = 2; goto done; }
+    for (int i = 0; i < N; i++) {
+      lo[2 * i] = creal(lophase); lo[2 * i + 1] = cimag(lophase);
+      lofreq *= loaccel;
+      lophase *= lofreq;
+    }
+    if (e->set_dechirp(h, lo) != 0) { exitcode = 2; goto done; }
+  }
+  {
+    struct stat sb;
+    if (!o->quiet && fstat(fileno(in), &sb) == 0 && S_ISREG(sb.st_mode)) {
+      long long nsamples = sb.st_size / 4;
+      fprintf(err, "%s: demodulating %'lld bytes; %'lld samples; %'.2lf sec @ %'.1lf Hz\n", o->argv0,
+              (long long)sb.st_size, nsamples, nsamples / Samprate, Samprate);
+    }
+  }
+
+  for (;;) {
+    /* a whole block or nothing: the remainder of the input is dropped (pmdemod.c:206-216) */
+    size_t got = fread(iq, 4, (size_t)N, in);
+    if (got < (size_t)N) break;
+    if (e->load(h, iq, o->flip ? 1 : 0) != 0) { exitcode = 2; break; }
+
+    int firstbin, lastbin;
+    if (Search_width != 0 && cn0 > o->cn0_threshold) {       /* locked: search near the last carrier */
+      if (Carrier_search_freq - Search_width <= -Samprate / 2) firstbin = 0;
+      else { firstbin = (int)((Carrier_search_freq - Search_width) / Binsize); if (firstbin < 0) firstbin += N; }
+      if (Carrier_search_freq + Search_width >= Samprate / 2) lastbin = N / 2 - 1;
+      else { lastbin = (int)((Carrier_search_freq + Search_width) / Binsize); if (lastbin < 0) lastbin += N; }
+    } else { firstbin = 0; lastbin = N; }
+    if (firstbin > lastbin) { int t = firstbin; firstbin = lastbin; lastbin = t; }
+
+    pmdemod_peak pk;
+    if (e->fft_peak(h, firstbin, lastbin, &pk) != 0 || pk.peak < 0) { exitcode = 2; break; }
+    double ap = (pk.next_re * pk.peak_re + pk.next_im * pk.peak_im) / pk.maxenergy;
+    double dp = -ap / (1 - ap);
+    double am = (pk.prev_re * pk.peak_re + pk.prev_im * pk.peak_im) / pk.maxenergy;
+    double dm = am / (1 - am);
+    double d = (dp + dm) / 2 + tau(dp * dp) - tau(dm * dm);
+    double carrier_freq = Binsize * (pk.peak + d);
+    if (carrier_freq > Samprate / 2) carrier_freq -= Samprate;
+
+    double cstep = 2 * M_PI * carrier_freq / Samprate;
+    pmdemod_mix mx;
+    if (e->mix(h, cstep, &mx, out16) != 0) { exitcode = 2; break; }
+    cn0 = 10 * log10(Samprate * mx.amplitude * mx.amplitude / (2 * mx.diffsumsq));
+    if (cn0 > o->cn0_threshold) Carrier_search_freq = carrier_freq;
+    if (!o->quiet)
+      fprintf(err, "%s: sample %'lld (%'.3lf sec, %s); carrier %'.1lf Hz; C/No = %'.2lf dB%s\n", o->argv0,
+              total_samples, total_samples / Samprate, isee3_format_hms(total_samples / Samprate), carrier_freq,
+              cn0, cn0 >= o->cn0_threshold ? " locked" : "");
+    if (report && nb < report_cap) { report[nb].peak = pk.peak; report[nb].carrier_freq = carrier_freq; report[nb].cn0 = cn0; }
+    nb++;
+    fwrite(out16, sizeof(int16_t), (size_t)N, out);
+    fflush(out);
+    total_samples += N;
+  }
+done:
+  if (nreport) *nreport = nb;
+  if (h) e->destroy(h);
+  free(iq); free(out16); free(lo);
+  return exitcode;
+}

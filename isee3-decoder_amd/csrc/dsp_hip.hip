@@ -1,0 +1,563 @@
+// dsp_hip.hip -- pmdemod / symdemod kernels for MI355X (gfx950) behind include/isee3_dsp_hip.h.
+//
+// Everything here is HBM-bandwidth work on small per-element arithmetic: no MFMA, no LDS tiling
+// beyond block reductions.  Built with -ffp-contract=off: the reference's double arithmetic is
+// non-fused (x86-64 baseline), and symdemod's output must be byte-identical.
+//
+// symdemod (symdemod.c:202-335): the window's samples get an exact int64 prefix sum, after which
+//   every integrate-and-dump value is a difference of prefix entries.  timesearch = one thread per
+//   timing offset, walking the symbols in order so the double energy accumulation rounds exactly
+//   as the reference's loop does; adjacent threads read adjacent prefix entries (coalesced).
+// pmdemod (pmdemod.c:204-368): int16 IQ -> double2, Stockham radix-2 double-precision FFT
+//   (ping-pong in HBM, unit-stride reads), |X|^2 arg-max with the reference's "last maximum wins"
+//   rule, closed-form carrier spin-down (see carrier_params.c), two tree reductions, quantise.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#pragma GCC visibility push(default)
+#include "../../include/isee3_dsp_hip.h"
+extern "C" void pmd_carrier_params(double cstep, uint64_t *u_hi, uint64_t *u_lo, double *logrho);
+#pragma GCC visibility pop
+
+static thread_local char g_err[512] = "";
+static int g_device = -1;
+extern "C" const char *isee3dsp_last_error(void) { return g_err; }
+extern "C" int isee3dsp_set_device(int dev) {
+  if (hipSetDevice(dev) != hipSuccess) return -1;
+  g_device = dev;
+  return 0;
+}
+#define CHK(expr)                                                                                \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      snprintf(g_err, sizeof g_err, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      goto fail;                                                                                 \
+    }                                                                                            \
+  } while (0)
+
+static int grow(void **p, size_t *cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  if (hipMalloc(p, need) != hipSuccess) return -1;
+  *cap = need;
+  return 0;
+}
+
+// ===========================================================================================
+// symdemod
+// ===========================================================================================
+#define SCAN_PER_THREAD 16
+#define SCAN_BLOCK (256 * SCAN_PER_THREAD)
+
+struct Symd {
+  int dev; hipStream_t st;
+  int cap, n;
+  int16_t *d_s; long long *d_P; long long *d_blk; int nblk_cap;
+  void *d_idx; size_t idx_cap;
+  void *d_e; size_t e_cap;
+  void *d_out; size_t out_cap;
+  void *d_sym; size_t sym_cap;
+};
+
+__device__ __forceinline__ long long wave_incl_scan(long long v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    long long u = __shfl_up(v, o, 64);
+    if ((int)(threadIdx.x & 63) >= o) v += u;
+  }
+  return v;
+}
+
+// block-local sums of 4096 samples
+__global__ __launch_bounds__(256) void k_scan_partial(const int16_t *__restrict__ s, int n,
+                                                      long long *__restrict__ blk) {
+  long long base = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  long long acc = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) if (base + k < n) acc += s[base + k];
+  acc = wave_incl_scan(acc);
+  __shared__ long long ws[4];
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// exclusive scan of the block sums by one block
+__global__ __launch_bounds__(256) void k_scan_blocks(long long *blk, int nblk) {
+  __shared__ long long carry, ws[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 256) {
+    int i = base + threadIdx.x;
+    long long v = i < nblk ? blk[i] : 0;
+    long long inc = wave_incl_scan(v);
+    if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    long long off = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += ws[w];
+    if (i < nblk) blk[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = off + inc;
+    __syncthreads();
+  }
+}
+// P[0] = 0, P[i+1] = sum(s[0..i])
+__global__ __launch_bounds__(256) void k_scan_final(const int16_t *__restrict__ s, int n,
+                                                    const long long *__restrict__ blk,
+                                                    long long *__restrict__ P) {
+  long long base = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  long long v[SCAN_PER_THREAD], acc = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { acc += (base + k < n) ? s[base + k] : 0; v[k] = acc; }
+  long long inc = wave_incl_scan(acc);
+  __shared__ long long ws[4];
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  long long off = blk[blockIdx.x] + inc - acc;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += ws[w];
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) if (base + k < n) P[base + k + 1] = off + v[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) P[0] = 0;
+}
+
+// symdemod.c:260-335: thread t = timing offset, sequential over symbols
+__global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__ P, int lo,
+                                                   const int *__restrict__ sw, int symbolclocks,
+                                                   int nsymbols, int noff, double *__restrict__ energies) {
+  int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= noff) return;
+  const long long *Pb = P + lo + t;
+  double energy = 0;
+  int k = 0;
+  for (int i = 0; i < nsymbols; i++) {
+    long long sym = 0;
+    for (int j = 0; j < symbolclocks; j++, k += 2) {
+      long long a = Pb[sw[k]], b = Pb[sw[k + 1]], c = Pb[sw[k + 2]];
+      sym += -(b - a) + (c - b);
+    }
+    energy += (double)(sym * sym);
+  }
+  energies[t] = energy;
+}
+
+// symdemod.c:202-256: one thread per symbol; a single lane then sums sym^2 in order
+__global__ __launch_bounds__(256) void k_demod(const long long *__restrict__ P, const int *__restrict__ edges,
+                                               int symbolclocks, int nsymbols, double gain,
+                                               uint8_t *__restrict__ out, long long *__restrict__ symv) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nsymbols) return;
+  long long integ = 0;
+  int k = 2 * i * symbolclocks;
+  for (int j = 0; j < symbolclocks; j++, k += 2) {
+    long long a = P[edges[k]], b = P[edges[k + 1]], c = P[edges[k + 2]];
+    integ += -(b - a) + (c - b);
+  }
+  symv[i] = integ;
+  if (gain != 0 && out) {
+    double scaled = gain * (double)integ + 128;
+    if (scaled > 255) scaled = 255; else if (scaled < 0) scaled = 0;
+    out[i] = (unsigned char)scaled;
+  }
+}
+__global__ void k_seq_energy(const long long *__restrict__ symv, int nsymbols, double *energy) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double e = 0;
+  for (int i = 0; i < nsymbols; i++) e += (double)(symv[i] * symv[i]);
+  *energy = e;
+}
+
+extern "C" void *symd_create(int max_samples) {
+  Symd *h = (Symd *)calloc(1, sizeof(Symd));
+  if (!h) return nullptr;
+  h->dev = g_device >= 0 ? g_device : 0;
+  h->cap = max_samples > 0 ? max_samples : 1;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  CHK(hipMalloc(&h->d_s, sizeof(int16_t) * (size_t)h->cap));
+  CHK(hipMalloc(&h->d_P, sizeof(long long) * ((size_t)h->cap + 1)));
+  h->nblk_cap = (h->cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  CHK(hipMalloc(&h->d_blk, sizeof(long long) * (size_t)h->nblk_cap));
+  return h;
+fail:
+  symd_destroy(h);
+  return nullptr;
+}
+extern "C" void symd_destroy(void *p) {
+  Symd *h = (Symd *)p;
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  (void)hipFree(h->d_s); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
+  (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym);
+  free(h);
+}
+extern "C" int symd_load(void *p, const int16_t *samples, int n, int is_dev) {
+  Symd *h = (Symd *)p;
+  if (!h || n < 0 || n > h->cap) { snprintf(g_err, sizeof g_err, "symd_load: bad size %d (cap %d)", n, h ? h->cap : 0); return -1; }
+  CHK(hipSetDevice(h->dev));
+  CHK(hipMemcpyAsync(h->d_s, samples, sizeof(int16_t) * (size_t)n,
+                     is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->st));
+  h->n = n;
+  if (n > 0) {
+    int nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    k_scan_partial<<<nblk, 256, 0, h->st>>>(h->d_s, n, h->d_blk);
+    k_scan_blocks<<<1, 256, 0, h->st>>>(h->d_blk, nblk);
+    k_scan_final<<<nblk, 256, 0, h->st>>>(h->d_s, n, h->d_blk, h->d_P);
+    CHK(hipGetLastError());
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks, int nsymbols, int noff,
+                               double *energies) {
+  Symd *h = (Symd *)p;
+  if (!h) return -1;
+  {
+    int nsw = 2 * symbolclocks * nsymbols + 1;
+    if (lo < 0 || noff < 1 || lo + noff - 1 + sw[nsw - 1] > h->n) {
+      snprintf(g_err, sizeof g_err, "symd_timesearch: window [%d, %d) outside the %d loaded samples", lo,
+               lo + noff - 1 + sw[nsw - 1], h->n);
+      return -1;
+    }
+    CHK(hipSetDevice(h->dev));
+    if (grow(&h->d_idx, &h->idx_cap, sizeof(int) * (size_t)nsw) || grow(&h->d_e, &h->e_cap, sizeof(double) * (size_t)noff)) {
+      snprintf(g_err, sizeof g_err, "symd_timesearch: allocation failed");
+      return -1;
+    }
+    CHK(hipMemcpyAsync(h->d_idx, sw, sizeof(int) * (size_t)nsw, hipMemcpyHostToDevice, h->st));
+    k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks, nsymbols,
+                                                     noff, (double *)h->d_e);
+    CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
+    CHK(hipStreamSynchronize(h->st));
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int symd_demod(void *p, const int *edges, int symbolclocks, int nsymbols, double gain,
+                          uint8_t *out, int out_is_dev, double *energy_sum) {
+  Symd *h = (Symd *)p;
+  if (!h) return -1;
+  {
+    int ne = 2 * symbolclocks * nsymbols + 1;
+    if (edges[0] < 0 || edges[ne - 1] > h->n) {
+      snprintf(g_err, sizeof g_err, "symd_demod: edges [%d, %d] outside the %d loaded samples", edges[0], edges[ne - 1], h->n);
+      return -1;
+    }
+    CHK(hipSetDevice(h->dev));
+    if (grow(&h->d_idx, &h->idx_cap, sizeof(int) * (size_t)ne) || grow(&h->d_sym, &h->sym_cap, sizeof(long long) * (size_t)nsymbols) ||
+        grow(&h->d_out, &h->out_cap, (size_t)nsymbols) || grow(&h->d_e, &h->e_cap, sizeof(double))) {
+      snprintf(g_err, sizeof g_err, "symd_demod: allocation failed");
+      return -1;
+    }
+    CHK(hipMemcpyAsync(h->d_idx, edges, sizeof(int) * (size_t)ne, hipMemcpyHostToDevice, h->st));
+    uint8_t *dst = (out && out_is_dev) ? out : (uint8_t *)h->d_out;
+    k_demod<<<(nsymbols + 255) / 256, 256, 0, h->st>>>(h->d_P, (const int *)h->d_idx, symbolclocks, nsymbols, gain,
+                                                       (gain != 0 && out) ? dst : nullptr, (long long *)h->d_sym);
+    if (energy_sum) {
+      k_seq_energy<<<1, 64, 0, h->st>>>((const long long *)h->d_sym, nsymbols, (double *)h->d_e);
+      CHK(hipMemcpyAsync(energy_sum, h->d_e, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    }
+    if (gain != 0 && out && !out_is_dev)
+      CHK(hipMemcpyAsync(out, h->d_out, (size_t)nsymbols, hipMemcpyDeviceToHost, h->st));
+    CHK(hipStreamSynchronize(h->st));
+  }
+  return 0;
+fail:
+  return -1;
+}
+
+// ===========================================================================================
+// pmdemod
+// ===========================================================================================
+struct Pmd {
+  int dev; hipStream_t st;
+  int N, logN;
+  double2 *buf, *spec, *tmp, *tw, *lo;   // lo = optional de-chirp table (conj applied at load)
+  int16_t *d_iq;
+  void *d_red; size_t red_cap;           // reduction scratch
+  int16_t *d_out16; double *d_pre;
+  int have_lo;
+};
+
+__global__ __launch_bounds__(256) void k_twiddles(double2 *tw, int N) {
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N / 2) return;
+  double s, c;
+  sincospi(-2.0 * (double)k / (double)N, &s, &c);
+  tw[k] = make_double2(c, s);
+}
+
+// pmdemod.c:209-229 (+ :237-243 when a de-chirp table is set)
+__global__ __launch_bounds__(256) void k_pmd_load(const short2 *__restrict__ iq, double2 *__restrict__ buf,
+                                                  const double2 *__restrict__ lo, int N, int flip) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  short2 v = iq[i];
+  double x = flip ? (double)v.y : (double)v.x, y = flip ? (double)v.x : (double)v.y;
+  if (lo) {                                // buffer[i] *= conj(lophase)
+    double pr = lo[i].x, pi = -lo[i].y;
+    double nx = x * pr - y * pi, ny = x * pi + y * pr;
+    x = nx; y = ny;
+  }
+  buf[i] = make_double2(x, y);
+}
+
+// one Stockham radix-2 stage: reads unit-stride, writes runs of s
+__global__ __launch_bounds__(256) void k_fft_stage(const double2 *__restrict__ x, double2 *__restrict__ y,
+                                                   const double2 *__restrict__ tw, int N, int s) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N / 2) return;
+  int q = t & (s - 1), ps = t - q;          // p * s
+  double2 a = x[t], b = x[t + N / 2], w = tw[ps];
+  double dr = a.x - b.x, di = a.y - b.y;
+  y[q + 2 * ps] = make_double2(a.x + b.x, a.y + b.y);
+  y[q + 2 * ps + s] = make_double2(dr * w.x - di * w.y, dr * w.y + di * w.x);
+}
+
+struct PeakRec { double e; int idx; int pad; };
+__device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) {
+  return e > be || (e == be && i > bi);     // ">=" while scanning upward == last maximum wins
+}
+__global__ __launch_bounds__(256) void k_peak_partial(const double2 *__restrict__ spec, int first, int last,
+                                                      PeakRec *__restrict__ part) {
+  double be = -1.0; int bi = -1;
+  for (int i = first + blockIdx.x * 256 + threadIdx.x; i < last; i += gridDim.x * 256) {
+    double2 v = spec[i];
+    double e = v.x * v.x + v.y * v.y;
+    if (peak_better(e, i, be, bi)) { be = e; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double oe = __shfl_xor(be, o, 64); int oi = __shfl_xor(bi, o, 64);
+    if (peak_better(oe, oi, be, bi)) { be = oe; bi = oi; }
+  }
+  __shared__ PeakRec ws[4];
+  if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6].e = be; ws[threadIdx.x >> 6].idx = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) if (peak_better(ws[w].e, ws[w].idx, be, bi)) { be = ws[w].e; bi = ws[w].idx; }
+    part[blockIdx.x].e = be; part[blockIdx.x].idx = bi;
+  }
+}
+__global__ void k_peak_final(const PeakRec *__restrict__ part, int nparts, const double2 *__restrict__ spec, int N,
+                             pmd_peak *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double be = -1.0; int bi = -1;
+  for (int p = 0; p < nparts; p++) if (peak_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
+  out->peak = bi; out->maxenergy = be;
+  if (bi >= 0) {
+    int next = (bi + 1) % N, prev = (N + bi - 1) % N;
+    out->peak_re = spec[bi].x; out->peak_im = spec[bi].y;
+    out->next_re = spec[next].x; out->next_im = spec[next].y;
+    out->prev_re = spec[prev].x; out->prev_im = spec[prev].y;
+  }
+}
+
+// carrier_i of pmdemod.c:332-335 in closed form (carrier_params.c)
+__device__ __forceinline__ double2 carrier_at(unsigned long long i, unsigned long long u_hi,
+                                              unsigned long long u_lo, double logrho) {
+  unsigned long long f = i * u_hi + __umul64hi(i, u_lo);     // frac(i * u) in 0.64 fixed point
+  double phi = (double)f * 5.42101086242752217e-20;           // 2^-64
+  double s, c;
+  sincospi(2.0 * phi, &s, &c);
+  double mag = 1.0 + (double)i * logrho;
+  return make_double2(mag * c, -(mag * s));
+}
+
+#define RED_BLOCKS 1024
+// pass 1: buf[i] *= carrier_i, partial sums of the result
+__global__ __launch_bounds__(256) void k_mix(double2 *__restrict__ buf, int N, unsigned long long u_hi,
+                                             unsigned long long u_lo, double logrho, double2 *__restrict__ part) {
+  double sr = 0, si = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    double2 v = buf[i], c = carrier_at((unsigned long long)i, u_hi, u_lo, logrho);
+    double nx = v.x * c.x - v.y * c.y, ny = v.x * c.y + v.y * c.x;
+    buf[i] = make_double2(nx, ny);
+    sr += nx; si += ny;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); si += __shfl_xor(si, o, 64); }
+  __shared__ double2 ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = make_double2(sr, si);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[blockIdx.x] = make_double2(ws[0].x + ws[1].x + ws[2].x + ws[3].x, ws[0].y + ws[1].y + ws[2].y + ws[3].y);
+}
+__global__ void k_sum2(const double2 *__restrict__ part, int n, double2 *out) {
+  __shared__ double2 ws[256];
+  double sr = 0, si = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { sr += part[i].x; si += part[i].y; }
+  ws[threadIdx.x] = make_double2(sr, si);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ws[threadIdx.x].x += ws[threadIdx.x + o].x; ws[threadIdx.x].y += ws[threadIdx.x + o].y; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = ws[0];
+}
+// pass 2 (pmdemod.c:341-348) + quantise (:360-368)
+__global__ __launch_bounds__(256) void k_rotate(double2 *__restrict__ buf, int N, double ur, double ui, double amp,
+                                                int16_t *__restrict__ out16, double *__restrict__ pre,
+                                                double2 *__restrict__ part) {
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    double2 v = buf[i];
+    double nx = v.x * ur - v.y * ui, ny = v.x * ui + v.y * ur;
+    buf[i] = make_double2(nx, ny);
+    double d = nx - amp;
+    acc += d * d;
+    double q = ny * 0.70710678118654752440;       // M_SQRT1_2
+    if (pre) pre[i] = q;
+    out16[i] = (short)q;                          // truncation toward zero, as the C cast
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ double ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], 0.0);
+}
+
+extern "C" void *pmd_create(int fftsize) {
+  Pmd *h = nullptr;
+  int lg = 0;
+  while ((1 << lg) < fftsize) lg++;
+  if (fftsize < 16 || (1 << lg) != fftsize || lg > 24) { snprintf(g_err, sizeof g_err, "pmd_create: fftsize %d not a power of two in [16, 2^24]", fftsize); return nullptr; }
+  h = (Pmd *)calloc(1, sizeof(Pmd));
+  if (!h) return nullptr;
+  h->dev = g_device >= 0 ? g_device : 0;
+  h->N = fftsize; h->logN = lg;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  CHK(hipMalloc(&h->buf, sizeof(double2) * (size_t)fftsize));
+  CHK(hipMalloc(&h->spec, sizeof(double2) * (size_t)fftsize));
+  CHK(hipMalloc(&h->tmp, sizeof(double2) * (size_t)fftsize));
+  CHK(hipMalloc(&h->tw, sizeof(double2) * (size_t)(fftsize / 2)));
+  CHK(hipMalloc(&h->d_iq, sizeof(int16_t) * 2 * (size_t)fftsize));
+  CHK(hipMalloc(&h->d_out16, sizeof(int16_t) * (size_t)fftsize));
+  CHK(hipMalloc(&h->d_pre, sizeof(double) * (size_t)fftsize));
+  h->red_cap = sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak) + sizeof(PeakRec) * RED_BLOCKS;
+  CHK(hipMalloc(&h->d_red, h->red_cap));
+  k_twiddles<<<(fftsize / 2 + 255) / 256, 256, 0, h->st>>>(h->tw, fftsize);
+  CHK(hipGetLastError());
+  CHK(hipStreamSynchronize(h->st));
+  return h;
+fail:
+  pmd_destroy(h);
+  return nullptr;
+}
+extern "C" void pmd_destroy(void *p) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red);
+  free(h);
+}
+// de-chirp LO table (N complex doubles = the lophase sequence of pmdemod.c:237-243, computed by the
+// host with the reference's own sequential recurrence); NULL switches de-chirp off
+extern "C" int pmd_set_dechirp(void *p, const double *lophase_ri) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return -1;
+  CHK(hipSetDevice(h->dev));
+  if (!lophase_ri) { h->have_lo = 0; return 0; }
+  if (!h->lo) CHK(hipMalloc(&h->lo, sizeof(double2) * (size_t)h->N));
+  CHK(hipMemcpy(h->lo, lophase_ri, sizeof(double2) * (size_t)h->N, hipMemcpyHostToDevice));
+  h->have_lo = 1;
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int pmd_load(void *p, const int16_t *iq, int is_dev, int flip) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return -1;
+  CHK(hipSetDevice(h->dev));
+  {
+    const int16_t *src = iq;
+    if (!is_dev) {
+      CHK(hipMemcpyAsync(h->d_iq, iq, sizeof(int16_t) * 2 * (size_t)h->N, hipMemcpyHostToDevice, h->st));
+      src = h->d_iq;
+    }
+    k_pmd_load<<<(h->N + 255) / 256, 256, 0, h->st>>>((const short2 *)src, h->buf, h->have_lo ? h->lo : nullptr, h->N, flip);
+    CHK(hipGetLastError());
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return -1;
+  if (firstbin < 0 || lastbin > h->N || firstbin > lastbin) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: bad bin range"); return -1; }
+  CHK(hipSetDevice(h->dev));
+  {
+    // logN stages ping-pong so that the last one lands in spec; buf is never written
+    const double2 *src = h->buf;
+    int s = 1;
+    for (int st = 0; st < h->logN; st++, s <<= 1) {
+      bool to_spec = ((h->logN - 1 - st) & 1) == 0;
+      double2 *dst = to_spec ? h->spec : h->tmp;
+      k_fft_stage<<<(h->N / 2 + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+      src = dst;
+    }
+    PeakRec *part = (PeakRec *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak));
+    pmd_peak *dres = (pmd_peak *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64));
+    int nb = (lastbin - firstbin + 255) / 256;
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    k_peak_partial<<<nb, 256, 0, h->st>>>(h->spec, firstbin, lastbin, part);
+    k_peak_final<<<1, 64, 0, h->st>>>(part, nb, h->spec, h->N, dres);
+    CHK(hipMemcpyAsync(out, dres, sizeof(pmd_peak), hipMemcpyDeviceToHost, h->st));
+    CHK(hipStreamSynchronize(h->st));
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *out16, double *pre, int out_is_dev) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return -1;
+  CHK(hipSetDevice(h->dev));
+  {
+    uint64_t u_hi, u_lo; double logrho;
+    pmd_carrier_params(cstep, &u_hi, &u_lo, &logrho);
+    double2 *part = (double2 *)h->d_red, *tot = part + RED_BLOCKS;
+    int nb = (h->N + 255) / 256; if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    k_mix<<<nb, 256, 0, h->st>>>(h->buf, h->N, u_hi, u_lo, logrho, part);
+    k_sum2<<<1, 256, 0, h->st>>>(part, nb, tot);
+    double2 dc;
+    CHK(hipMemcpyAsync(&dc, tot, sizeof dc, hipMemcpyDeviceToHost, h->st));
+    CHK(hipStreamSynchronize(h->st));
+    double dcr = dc.x / h->N, dci = dc.y / h->N;
+    double amp = hypot(dcr, dci);                 // cabs, pmdemod.c:337
+    double ur = dcr / amp, ui = -dci / amp;       // conj(dc) / amp, :338
+    int16_t *o16 = (out16 && out_is_dev) ? out16 : h->d_out16;
+    double *opre = pre ? (out_is_dev ? pre : h->d_pre) : nullptr;
+    k_rotate<<<nb, 256, 0, h->st>>>(h->buf, h->N, ur, ui, amp, o16, opre, part);
+    k_sum2<<<1, 256, 0, h->st>>>(part, nb, tot);
+    CHK(hipMemcpyAsync(&dc, tot, sizeof dc, hipMemcpyDeviceToHost, h->st));
+    if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
+    if (pre && !out_is_dev) CHK(hipMemcpyAsync(pre, h->d_pre, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
+    CHK(hipStreamSynchronize(h->st));
+    res->dc_re = dcr; res->dc_im = dci; res->amplitude = amp; res->diffsumsq = dc.x / h->N;
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int pmd_get_spectrum(void *p, double *out_ri) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return -1;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipMemcpy(out_ri, h->spec, sizeof(double2) * (size_t)h->N, hipMemcpyDeviceToHost));
+  return 0;
+fail:
+  return -1;
+}

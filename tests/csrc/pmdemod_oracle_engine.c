@@ -1,0 +1,65 @@
+/* Test harness: the PRODUCT's pmdemod host logic (cli/pmdemod_core.c) on a CPU engine built from the
+ * oracle's FFT and the reference's own per-sample recurrences.  TEST INFRASTRUCTURE ONLY. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../isee3-decoder_amd/cli/pmdemod_core.h"
+#include "../../oracle/oracle.h"
+
+typedef struct { int N; double *buf, *spec, *lo; } cpu_t;
+static void *c_create(int N) { cpu_t *c = calloc(1, sizeof *c); c->N = N; c->buf = malloc(16 * (size_t)N); c->spec = malloc(16 * (size_t)N); return c; }
+static int c_dechirp(void *h, const double *t) { cpu_t *c = h; c->lo = malloc(16 * (size_t)c->N); memcpy(c->lo, t, 16 * (size_t)c->N); return 0; }
+static int c_load(void *h, const int16_t *iq, int flip) {
+  cpu_t *c = h;
+  for (int i = 0; i < c->N; i++) {
+    double x = flip ? iq[2 * i + 1] : iq[2 * i], y = flip ? iq[2 * i] : iq[2 * i + 1];
+    if (c->lo) { double pr = c->lo[2 * i], pi = -c->lo[2 * i + 1]; double nx = x * pr - y * pi, ny = x * pi + y * pr; x = nx; y = ny; }
+    c->buf[2 * i] = x; c->buf[2 * i + 1] = y;
+  }
+  return 0;
+}
+static int c_peak(void *h, int a, int b, pmdemod_peak *o) {
+  cpu_t *c = h; int N = c->N;
+  orc_fft_forward(c->buf, c->spec, N);
+  int peak = -1; double mx = 0;
+  for (int i = a; i < b; i++) { double e = c->spec[2 * i] * c->spec[2 * i] + c->spec[2 * i + 1] * c->spec[2 * i + 1]; if (e >= mx) { mx = e; peak = i; } }
+  o->peak = peak; o->maxenergy = mx;
+  if (peak >= 0) {
+    int nx = (peak + 1) % N, pv = (N + peak - 1) % N;
+    o->peak_re = c->spec[2 * peak]; o->peak_im = c->spec[2 * peak + 1];
+    o->next_re = c->spec[2 * nx]; o->next_im = c->spec[2 * nx + 1];
+    o->prev_re = c->spec[2 * pv]; o->prev_im = c->spec[2 * pv + 1];
+  }
+  return 0;
+}
+static int c_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) {
+  cpu_t *c = h; int N = c->N;
+  double sr = cos(cstep), si = -sin(cstep), cr = 1, ci = 0, dcr = 0, dci = 0;
+  for (int i = 0; i < N; i++) {
+    double x = c->buf[2 * i], y = c->buf[2 * i + 1], nx = x * cr - y * ci, ny = x * ci + y * cr;
+    c->buf[2 * i] = nx; c->buf[2 * i + 1] = ny; dcr += nx; dci += ny;
+    double ncr = cr * sr - ci * si, nci = cr * si + ci * sr; cr = ncr; ci = nci;
+  }
+  dcr /= N; dci /= N;
+  double amp = hypot(dcr, dci), ur = dcr / amp, ui = -dci / amp, ds = 0;
+  for (int i = 0; i < N; i++) {
+    double x = c->buf[2 * i], y = c->buf[2 * i + 1], nx = x * ur - y * ui, ny = x * ui + y * ur;
+    ds += (nx - amp) * (nx - amp);
+    out16[i] = (short)(ny * M_SQRT1_2);
+  }
+  r->dc_re = dcr; r->dc_im = dci; r->amplitude = amp; r->diffsumsq = ds / N;
+  return 0;
+}
+static void c_destroy(void *h) { cpu_t *c = h; free(c->buf); free(c->spec); free(c->lo); free(c); }
+
+int main(int argc, char **argv) {
+  pmdemod_opts o;
+  int rc = pmdemod_parse_args(&o, argc, argv, stderr);
+  if (rc) return rc;
+  pmdemod_engine e = { c_create, c_dechirp, c_load, c_peak, c_mix, c_destroy };
+  pmdemod_block_report rep[64]; int n = 0;
+  rc = pmdemod_run(&o, &e, stdin, stdout, stderr, rep, 64, &n);
+  for (int i = 0; i < n; i++) fprintf(stderr, "REPORT %d %.17g %.17g\n", rep[i].peak, rep[i].carrier_freq, rep[i].cn0);
+  return rc;
+}

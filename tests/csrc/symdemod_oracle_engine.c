@@ -1,0 +1,45 @@
+/* Test harness: the PRODUCT's symdemod host logic (cli/symdemod_core.c) on a plain CPU engine, so the
+ * buffer / boundary / selection logic can be checked against the reference's symdemod output
+ * without a GPU.  TEST INFRASTRUCTURE ONLY. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../isee3-decoder_amd/cli/symdemod_core.h"
+
+typedef struct { int16_t *s; int n, cap; } cpu_t;
+static void *c_create(int cap) { cpu_t *c = calloc(1, sizeof *c); c->s = malloc(sizeof(int16_t) * (size_t)cap); c->cap = cap; return c; }
+static int c_load(void *h, const int16_t *s, int n) { cpu_t *c = h; memcpy(c->s, s, sizeof(int16_t) * (size_t)n); c->n = n; return 0; }
+static long long seg(const cpu_t *c, int a, int b) { long long v = 0; for (int i = a; i < b; i++) v += c->s[i]; return v; }
+static int c_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) {
+  cpu_t *c = h;
+  for (int t = 0; t < noff; t++) {
+    double e = 0; int k = 0;
+    for (int i = 0; i < ns; i++) {
+      long long sym = 0;
+      for (int j = 0; j < sc; j++, k += 2)
+        sym += -seg(c, lo + t + sw[k], lo + t + sw[k + 1]) + seg(c, lo + t + sw[k + 1], lo + t + sw[k + 2]);
+      e += sym * sym;
+    }
+    en[t] = e;
+  }
+  return 0;
+}
+static int c_demod(void *h, const int *ed, int sc, int ns, double gain, uint8_t *out, double *esum) {
+  cpu_t *c = h; double e = 0; int k = 0;
+  for (int i = 0; i < ns; i++) {
+    long long v = 0;
+    for (int j = 0; j < sc; j++, k += 2) v += -seg(c, ed[k], ed[k + 1]) + seg(c, ed[k + 1], ed[k + 2]);
+    if (gain != 0 && out) { double s = gain * v + 128; if (s > 255) s = 255; else if (s < 0) s = 0; out[i] = (unsigned char)s; }
+    e += v * v;
+  }
+  if (esum) *esum = e;
+  return 0;
+}
+static void c_destroy(void *h) { cpu_t *c = h; free(c->s); free(c); }
+
+int main(int argc, char **argv) {
+  symdemod_opts o;
+  symdemod_parse_args(&o, argc, argv);
+  symdemod_engine e = { c_create, c_load, c_ts, c_demod, c_destroy };
+  return symdemod_run(&o, &e, 0, stdout, stderr) ? 2 : 0;
+}

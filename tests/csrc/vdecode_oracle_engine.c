@@ -1,0 +1,31 @@
+/* Test harness: the PRODUCT's vdecode host logic (isee3-decoder_amd/cli/vdecode_core.c) driven by
+ * the CPU oracle instead of the HIP library, so the pairing / phase-flip / start-up / statistics
+ * logic can be checked against the reference's vdecode output on a machine without a GPU.
+ * TEST INFRASTRUCTURE ONLY. */
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../isee3-decoder_amd/cli/vdecode_core.h"
+#include "../../oracle/oracle.h"
+
+static void *eng_create(int len) { return orc_v224_create(len, ORC_V224_FAST); }
+static int eng_init(void *h, int s) { return orc_v224_init(h, s); }
+static unsigned long long steps;
+static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out) {
+  for (int i = 0; i < nbits; i++) {
+    orc_v224_update(h, syms + 2 * i, 1);
+    steps++;
+    out[i] = steps >= (unsigned long long)delay ? (unsigned char)orc_v224_decodebit(h, delay, 0) : 0xff;
+  }
+  return 0;
+}
+static void eng_destroy(void *h) { orc_v224_delete(h); }
+
+int main(int argc, char **argv) {
+  vdecode_opts o;
+  vdecode_result r;
+  vdecode_parse_args(&o, argc, argv);
+  vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 0 };
+  int rc = vdecode_run(&o, &e, 0, stdout, stderr, &r);
+  fprintf(stderr, "RESULT bits=%llu symerrs=%llu flips=%d\n", r.bits_out, r.symerrs_total, r.flips);
+  return rc ? 2 : 0;
+}

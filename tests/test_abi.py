@@ -45,3 +45,23 @@ def test_no_cpu_fallback_without_gpu():
     assert L.init_viterbi224(None, 0) == -1            # NULL handle convention, port.c:38-39
     assert L.update_viterbi224_blk(None, None, 0) == -1
     assert L.decodebit_viterbi224(None, 1, 0) == -1
+
+
+def test_dsp_header_vs_library():
+    pkg = load_pkg()
+    so = pkg.lib_path("libisee3dsp_hip.so")
+    assert os.path.exists(so), "build() must produce %s" % so
+    L = C.CDLL(so)
+    txt = open(os.path.join(ROOT, "include", "isee3_dsp_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b((?:symd|pmd|isee3dsp)_[a-z0-9_]+)\s*\(", txt)))
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(L, n), "missing export %s" % n
+    assert names == sorted(pkg.DSP_SYMBOLS)
+
+
+def test_cli_binaries_built():
+    pkg = load_pkg()
+    for exe in ("vdecode", "symdemod", "pmdemod"):
+        assert os.access(pkg.cli_path(exe), os.X_OK)

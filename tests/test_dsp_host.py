@@ -1,0 +1,96 @@
+"""CPU: host logic of the product's symdemod / pmdemod pipe stages (C, cli/*_core.c) on plain CPU
+engines.  symdemod is pinned to the reference's own stdout (tests/golden/symdemod_cli.npz);
+pmdemod is compared with the oracle restatement (PARITY UNPINNED: the reference stage needs FFTW3,
+which the image lacks) and the oracle FFT is cross-checked against numpy."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT
+
+BUILD = os.path.join(ROOT, "tests", "_build")
+CLI = os.path.join(ROOT, "isee3-decoder_amd", "cli")
+SG = os.path.join(orc.GOLDEN, "symdemod_cli.npz")
+PG = os.path.join(orc.GOLDEN, "pmdemod_oracle.npz")
+
+
+def _build(name, srcs, extra=()):
+    orc.lib()
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, name)
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe] + srcs + list(extra) + ["-lm"], check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def sym_harness():
+    return _build("symdemod_cpu_test", [os.path.join(ROOT, "tests", "csrc", "symdemod_oracle_engine.c"),
+                                        os.path.join(CLI, "symdemod_core.c")])
+
+
+@pytest.fixture(scope="module")
+def pm_harness():
+    return _build("pmdemod_cpu_test", [os.path.join(ROOT, "tests", "csrc", "pmdemod_oracle_engine.c"),
+                                       os.path.join(CLI, "pmdemod_core.c")],
+                  ["-L" + orc.ORACLE_DIR, "-loracle", "-Wl,-rpath," + orc.ORACLE_DIR, "-fopenmp"])
+
+
+def sym_input(z, name):
+    if name + "/in" in z:
+        return z[name + "/in"]
+    g = z[name + "/gen"]
+    bb, _ = orc.gen_baseband(int(g[0]), g[1], g[2], g[3], g[4], g[5])
+    import hashlib
+    assert hashlib.sha256(bb.tobytes()).hexdigest() == str(z[name + "/in_sha256"])
+    return bb
+
+
+@pytest.mark.parametrize("name", [str(n) for n in np.load(SG)["names"]])
+def test_symdemod_host_logic_vs_reference_stdout(sym_harness, name):
+    z = np.load(SG)
+    bb = sym_input(z, name)
+    p = subprocess.run([sym_harness] + [str(a) for a in z[name + "/args"]], input=bb.tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600)
+    assert p.stdout == z[name + "/stdout"].tobytes()
+
+
+def _pm_args(cfg):
+    a = ["-q", "-r", repr(float(cfg[0])), "-b", repr(float(cfg[1]))]
+    if cfg[2]: a += ["-S", repr(float(cfg[2]))]
+    if cfg[3]: a += ["-W", repr(float(cfg[3]))]
+    if cfg[4]: a += ["-D", repr(float(cfg[4]))]
+    if cfg[6]: a += ["-f"]
+    return a
+
+
+@pytest.mark.parametrize("name", [str(n) for n in np.load(PG)["names"]])
+def test_pmdemod_host_logic_vs_oracle(pm_harness, name):
+    z = np.load(PG)
+    p = subprocess.run([pm_harness] + _pm_args(z[name + "/cfg"]), input=z[name + "/iq"].tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600)
+    out = np.frombuffer(p.stdout, dtype=np.int16)
+    assert np.array_equal(out, z[name + "/out"])       # same FFT, same recurrences => identical
+    rep = [l.split() for l in p.stderr.decode().splitlines() if l.startswith("REPORT")]
+    assert [int(r[1]) for r in rep] == list(z[name + "/peak"])
+    assert np.allclose([float(r[2]) for r in rep], z[name + "/carrier_freq"], rtol=0, atol=1e-9)
+
+
+def test_oracle_fft_vs_numpy():
+    rng = np.random.default_rng(5)
+    for n in (16, 1024, 1 << 15):
+        x = rng.normal(size=n) + 1j * rng.normal(size=n)
+        got, want = orc.fft_forward(x), np.fft.fft(x)
+        assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+
+
+def test_pmdemod_oracle_recovers_carrier():
+    """sanity of the restatement: carrier estimate within a small fraction of a bin, lock reported"""
+    iq, _ = orc.gen_iq(77, 16384.0, 1.0, fc_hz=1000.25, amp=3000.0, cn0_dbhz=50.0)
+    out, pre, rep, N = orc.pmdemod(iq, samprate=16384.0, binsize=4.0)
+    assert N == 4096 and len(rep) == 4
+    for r in rep:
+        assert abs(r["carrier_freq"] - 1000.25) < 0.5 and r["cn0"] > 40
+    assert np.array_equal(out, pre.astype(np.int16))    # C cast = truncation toward zero

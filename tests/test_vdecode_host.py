@@ -1,0 +1,53 @@
+"""CPU: the product's vdecode host logic (pairing, phase auto-flip, start-up suppression; C code in
+isee3-decoder_amd/cli/vdecode_core.c) reproduces the reference vdecode's stdout byte for byte when
+driven by the oracle engine; and the oracle's own vdecode restatement does too."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT
+
+G = os.path.join(orc.GOLDEN, "vdecode_cli.npz")
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+
+def _names():
+    return [str(n) for n in np.load(G)["names"]]
+
+
+def _args(z, name):
+    return [a for a in z[name + "/args"] if a]
+
+
+@pytest.fixture(scope="module")
+def harness():
+    orc.lib()
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "vdecode_oracle_test")
+    src = [os.path.join(ROOT, "tests", "csrc", "vdecode_oracle_engine.c"),
+           os.path.join(ROOT, "isee3-decoder_amd", "cli", "vdecode_core.c")]
+    subprocess.run(["gcc", "-O2", "-o", exe] + src + ["-L" + orc.ORACLE_DIR, "-loracle",
+                   "-Wl,-rpath," + orc.ORACLE_DIR, "-fopenmp", "-lm"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("name", _names())
+def test_host_logic_with_oracle_engine(harness, name):
+    z = np.load(G)
+    p = subprocess.run([harness, "-q"] + _args(z, name), input=z[name + "/syms"].tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600)
+    assert p.stdout == z[name + "/stdout"].tobytes()
+    if name == "flip":
+        assert b"flips=1" in p.stderr
+
+
+@pytest.mark.parametrize("name", ["startphase_p", "delay_too_small"])
+def test_oracle_vdecode_restatement(name):
+    z = np.load(G)
+    args = _args(z, name)
+    delay = int(args[args.index("-d") + 1]) if "-d" in args else 200
+    out, st = orc.vdecode(z[name + "/syms"], delay, int("-p" in args), "-F" in args)
+    assert out == z[name + "/stdout"].tobytes()
