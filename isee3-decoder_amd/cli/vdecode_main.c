@@ -8,7 +8,12 @@
 #include "vdecode_core.h"
 #include "../../include/viterbi224_hip.h"
 
-static void *eng_create(int len) { return create_viterbi224(len); }
+static int g_chunk = 1020;
+static void *eng_create(int len) {
+  void *h = create_viterbi224(len);
+  if (h) v224hip_set_option(h, "chunk", g_chunk);
+  return h;
+}
 static int eng_init(void *h, int s) { return init_viterbi224(h, s); }
 static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out) {
   return v224hip_stream_decode(h, syms, nbits, delay, out);
@@ -23,6 +28,7 @@ int main(int argc, char **argv) {
   vdecode_parse_args(&o, argc, argv);
   int chunk = getenv("V224HIP_CHUNK") ? atoi(getenv("V224HIP_CHUNK")) : 1020;
   if (chunk < 1) chunk = 1020;
+  g_chunk = chunk;
   vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 2 * chunk };
   if (vdecode_run(&o, &e, 0, stdout, stderr, &r) != 0) {
     fprintf(stderr, "%s: decoder engine failed: %s\n", o.argv0, v224hip_last_error());

@@ -321,7 +321,7 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   if (v->K < 1) v->K = 1;
   if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;
   v->dev = g_device >= 0 ? g_device : env_int("V224HIP_DEVICE", 0);
-  v->chunk = env_int("V224HIP_CHUNK", 1024);
+  v->chunk = env_int("V224HIP_CHUNK", 1020);   // multiple of 2,3,4,5,6: no ragged pass per chunk
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
