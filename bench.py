@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--engine", type=int, default=-1)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--segments-per-gpu", type=int, default=1,
+                    help="independent streams decoded concurrently on each GPU (own HIP streams)")
     ap.add_argument("--cpu-bits", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
@@ -100,43 +102,36 @@ def main():
     from importlib import import_module
     synth = import_module("isee3_decoder_amd.synth")
 
+    harness = import_module("isee3_decoder_amd.harness")
     nbits = a.symbols // 2
-    syms, bits, noise_mask = synth.coded_stream(1000 + rank, nbits, 3.0, 24.0, 1.0)
-    d_syms = pkg.DeviceBuffer.from_numpy(syms)
-    d_out = pkg.DeviceBuffer(nbits)
-
-    dec0 = pkg.Viterbi224(8, a.engine, a.k)           # probe defaults
+    nseg = world * a.segments_per_gpu
+    mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
     chunk = a.chunk or 1020
-    dec0.close()
-    dec = pkg.Viterbi224(a.delay + 2 * chunk, a.engine, a.k)
-    dec.set_option("chunk", chunk)
+    segs = []
+    for g in mine:
+        syms, bits, noise_mask = synth.coded_stream(1000 + g, nbits, 3.0, 24.0, 1.0)
+        dec = pkg.Viterbi224(a.delay + 2 * chunk, a.engine, a.k)
+        dec.set_option("chunk", chunk)
+        segs.append(dict(dec=dec, d_syms=pkg.DeviceBuffer.from_numpy(syms), d_out=pkg.DeviceBuffer(nbits),
+                         bits=bits, noise_mask=noise_mask))
+    dec = segs[0]["dec"]
 
     def step():
-        dec.init(0)
-        dec.stream_decode_dev(d_syms, nbits, a.delay, d_out)
+        # every segment has its own decoder and HIP streams: the enqueues below return at once and
+        # the segments' kernels run concurrently on the device
+        for sg in segs:
+            sg["dec"].init(0)
+            sg["dec"].stream_decode_dev(sg["d_syms"], nbits, a.delay, sg["d_out"])
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    fence()
+    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
+    harness.timed_steps(step, 0, a.warmup, fence)
     dec.set_option("profile", 4)
     dec.acs_stats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = harness.timed_steps(step, a.steps, 0, fence)
     launches, ms, steps_timed = dec.acs_stats()
     dec.set_option("profile", 0)
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, "cuda")
+    d_out, bits, noise_mask = segs[0]["d_out"], segs[0]["bits"], segs[0]["noise_mask"]
 
     # sanity: decoded bits equal sent bits away from the noise blocks (does not replace tests/)
     out = d_out.to_numpy(np.uint8)
@@ -149,7 +144,7 @@ def main():
     ber = float(np.mean(dec_bits[clean] != ref_bits[clean])) if clean.any() else -1.0
 
     if rank == 0:
-        total_syms = 2 * nbits * world * a.steps
+        total_syms = 2 * nbits * nseg * a.steps
         avg_ms = ms / launches if launches else float("nan")
         steps_per_launch = steps_timed / launches if launches else 0
         ach = ALG_BYTES_PER_STEP * steps_per_launch / (avg_ms * 1e-3) / 1e9 if launches else None
@@ -164,7 +159,7 @@ def main():
                                    "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
                        "engine": "fused" if dec.L.v224hip_stream_chunk(dec.h) and a.engine != 0 else "simple",
                        "k": a.k or int(os.environ.get("V224HIP_K", "5")), "chunk_bits": chunk,
-                       "segments_per_gpu": 1, "parallelism": "segments x%d" % world},
+                       "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
                          "traffic": None,
@@ -177,7 +172,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(a.cpu_bits)
             res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
-    dec.close()
+    for sg in segs:
+        sg["dec"].close()
     if world > 1:
         dist.destroy_process_group()
 

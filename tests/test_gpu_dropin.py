@@ -1,0 +1,41 @@
+"""GPU: the drop-in claim itself.  The reference's UNMODIFIED vdecode.c and vtest224.c, linked against
+libviterbi224_hip.so in place of viterbi224_port.o (oracle/Makefile -> oracle/_ref/*_hiplink; prebuilt
+in the build container, /root/reference is not needed at run time), behave like the port build."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+VG = os.path.join(orc.GOLDEN, "vdecode_cli.npz")
+
+
+def _exe(name):
+    p = os.path.join(orc.REF_DIR, name)
+    if not os.path.exists(p):
+        pytest.skip("%s not prebuilt (oracle/_ref travels from the build container)" % name)
+    return p
+
+
+@pytest.mark.parametrize("name", ["forced_F", "delay64"])
+def test_reference_vdecode_source_on_hip_library(name):
+    z = np.load(VG)
+    args = ["-q"] + [a for a in z[name + "/args"] if a]
+    p = subprocess.run([_exe("vdecode_hiplink")] + args, input=z[name + "/syms"].tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    assert p.stdout == z[name + "/stdout"].tobytes()
+
+
+def test_reference_vtest224_source_on_hip_library():
+    """vtest224 -e 5: random frames through its own AWGN channel; at 5 dB the decoder must be clean."""
+    p = subprocess.run([_exe("vtest224_hiplink"), "-l", "512", "-n", "3", "-e", "5"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    m = re.search(rb"BER (\d+)/(\d+).*FER (\d+)/(\d+)", p.stdout)
+    assert m, p.stdout
+    assert int(m.group(1)) == 0 and int(m.group(2)) == 3 * 512 and int(m.group(3)) == 0
