@@ -106,7 +106,8 @@ def main():
     nbits = a.symbols // 2
     nseg = world * a.segments_per_gpu
     mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
-    chunk = a.chunk or 1020
+    eng = a.engine if a.engine >= 0 else int(os.environ.get("V224HIP_ENGINE", "2"))
+    chunk = a.chunk or (1024 if eng == 2 else 1020)
     segs = []
     for g in mine:
         syms, bits, noise_mask = synth.coded_stream(1000 + g, nbits, 3.0, 24.0, 1.0)
@@ -157,13 +158,14 @@ def main():
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "viterbi224 ACS+chainback streaming, 2^23 states, 8-bit soft syms, "
                                    "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
-                       "engine": "fused" if dec.L.v224hip_stream_chunk(dec.h) and a.engine != 0 else "simple",
-                       "k": a.k or int(os.environ.get("V224HIP_K", "5")), "chunk_bits": chunk,
+                       "engine": {0: "simple", 1: "fused", 2: "lds8"}[eng],
+                       "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8}[eng],
+                       "chunk_bits": chunk,
                        "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
                          "traffic": None,
-                         "kernel": "k_acs_fused" if a.engine != 0 else "k_acs_simple",
+                         "kernel": {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8"}[eng],
                          "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "launches_timed": launches},
             "check": {"ber_clean": ber, "bits": int(clean.sum())},

@@ -21,10 +21,16 @@
 // row layout codes (rowmeta[row]): 0 = port bit order; else (K << 8) | stage for fused passes
 #define V224_META_PORT 0u
 
+// Minimum tracking without atomics: launch n writes one minimum per workgroup into
+// blkmin[(n+1)&1][blockIdx] and the count into nmin[(n+1)&1]; every workgroup of launch n+1 reduces
+// that small array itself (L2-resident, hidden behind its metric loads).  A single atomicMin slot
+// costs ~12 ns per workgroup (same-address atomics serialise): 6 us of a 17 us launch.
+#define V224_MAXBLK 4096
 struct V224Dev {
-  unsigned slot[4];        // rotating min slots: launch n reads slot[n%3], atomicMin's slot[(n+1)%3]
   long long off;           // true metric = stored + off
+  unsigned nmin[2];
   unsigned scratch[4];     // argmin / max / misc reductions
+  unsigned blkmin[2][V224_MAXBLK];
 };
 
 #define HIPCHK(expr)                                                                   \

@@ -13,7 +13,7 @@
 //             offset can be subtracted at will (struct V224Dev::off keeps the running total).
 //   decisions ring of `len` rows x 1 MiB; rowmeta[row] says in which bit order the row was
 //             written (port order by the simple engine, permuted by the fused engine).
-//   V224Dev   min slots + offset, updated by the kernels themselves (no host round trip).
+//   V224Dev   per-workgroup minima + running offset, updated by the kernels themselves.
 //
 // Engines:
 //   SIMPLE  one trellis step per launch.  Thread t owns butterflies 16t..16t+15: two 32-byte
@@ -21,6 +21,8 @@
 //           decision dword in port order.  34.6 MB of HBM traffic per step.
 //   FUSED   see v224_fused.hip.inc: K steps per launch with the path metrics of 2^K states held
 //           in packed-u16 VGPRs, so metric traffic drops to 32 MiB / K per step.
+//   LDS     see v224_lds.hip.inc: 8 steps per launch, 32 KiB tiles staged in LDS, two register
+//           levels of 4 steps each, lane-contiguous stores.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_init(uint16_t *m, unsigned start, V224D
   v.x = v.y = v.z = v.w = fill;
   reinterpret_cast<uint4 *>(m)[t] = v;
   if (t == 0) {
-    ds->slot[0] = V224_BASE; ds->slot[1] = 0xffffffffu; ds->slot[2] = 0xffffffffu; ds->slot[3] = 0;
+    ds->blkmin[0][0] = V224_BASE; ds->nmin[0] = 1; ds->nmin[1] = 0;
     ds->off = -(long long)V224_BASE;
   }
   (void)rowmeta; (void)len;
@@ -108,6 +110,35 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     v = w < v ? w : v;
   }
   return v;
+}
+
+// minimum of the metrics this launch reads = min over the previous launch's per-workgroup minima.
+// Called by every thread of a 256-thread workgroup (contains a barrier).
+__device__ __forceinline__ unsigned input_min(const V224Dev *ds, unsigned pass) {
+  const unsigned *a = ds->blkmin[pass & 1];
+  const unsigned n = ds->nmin[pass & 1];
+  unsigned m = 0xffffffffu;
+  for (unsigned i = threadIdx.x; i < n; i += 256) { unsigned v = a[i]; m = v < m ? v : m; }
+  m = wave_min_u32(m);
+  __shared__ unsigned s_in[4];
+  if ((threadIdx.x & 63) == 0) s_in[threadIdx.x >> 6] = m;
+  __syncthreads();
+  unsigned x = s_in[0] < s_in[1] ? s_in[0] : s_in[1];
+  unsigned y = s_in[2] < s_in[3] ? s_in[2] : s_in[3];
+  return x < y ? x : y;
+}
+// publish this workgroup's output minimum (mn already wave-reduced); thread 0 of block 0 also keeps
+// the running offset and the entry count
+__device__ __forceinline__ void output_min(V224Dev *ds, unsigned pass, unsigned mn, long long off_add) {
+  __shared__ unsigned s_out[4];
+  if ((threadIdx.x & 63) == 0) s_out[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = s_out[0] < s_out[1] ? s_out[0] : s_out[1];
+    unsigned b = s_out[2] < s_out[3] ? s_out[2] : s_out[3];
+    ds->blkmin[(pass + 1) & 1][blockIdx.x] = a < b ? a : b;
+    if (blockIdx.x == 0) { ds->nmin[(pass + 1) & 1] = gridDim.x; ds->off += off_add; }
+  }
 }
 
 // parity of (2i & POLY1) for i = 0..15 as a 16-bit mask (bit n set => flip)
@@ -129,13 +160,13 @@ __global__ __launch_bounds__(256) void k_acs_simple(const uint16_t *__restrict__
                                                     V224Dev *ds, unsigned pass,
                                                     uint32_t *rowmeta, int rowidx) {
   const unsigned t = blockIdx.x * 256 + threadIdx.x;
-  const unsigned adj = ds->slot[pass % 3] - V224_BASE;   // wave-uniform scalar load
   const unsigned s0 = syms[0], s1 = syms[1];
   const unsigned c0 = s0 + 255 - s1, c1 = s0 + s1;
 
   const uint4 *pi = reinterpret_cast<const uint4 *>(oldm + 16 * t);
   const uint4 *pj = reinterpret_cast<const uint4 *>(oldm + V224_NBFLY + 16 * t);
   uint4 vi[2] = { pi[0], pi[1] }, vj[2] = { pj[0], pj[1] };
+  const unsigned adj = input_min(ds, pass) - V224_BASE;
   const unsigned *wi = reinterpret_cast<const unsigned *>(vi);
   const unsigned *wj = reinterpret_cast<const unsigned *>(vj);
 
@@ -167,25 +198,15 @@ __global__ __launch_bounds__(256) void k_acs_simple(const uint16_t *__restrict__
   row[t] = dec;
 
   mn = wave_min_u32(mn);
-  __shared__ unsigned smin[4];
-  if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = mn;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned a = smin[0] < smin[1] ? smin[0] : smin[1];
-    unsigned b = smin[2] < smin[3] ? smin[2] : smin[3];
-    atomicMin(&ds->slot[(pass + 1) % 3], a < b ? a : b);
-    if (blockIdx.x == 0) {
-      ds->slot[(pass + 2) % 3] = 0xffffffffu;       // read by launch pass-1, which has finished
-      ds->off += (long long)adj;
-      rowmeta[rowidx] = V224_META_PORT;
-    }
-  }
+  output_min(ds, pass, mn, (long long)(int)adj);      // adj can be negative after a fused pass
+  if (blockIdx.x == 0 && threadIdx.x == 0) rowmeta[rowidx] = V224_META_PORT;
 }
 
 // ------------------------------------------------------------------------------------------
 // decision-bit fetch (all layouts) and traceback kernels
 // ------------------------------------------------------------------------------------------
 #include "v224_fused.hip.inc"
+#include "v224_lds.hip.inc"
 
 __device__ __forceinline__ unsigned get_decision(const uint32_t *__restrict__ rows,
                                                  const uint32_t *__restrict__ rowmeta,
@@ -193,6 +214,7 @@ __device__ __forceinline__ unsigned get_decision(const uint32_t *__restrict__ ro
   const uint32_t *r = rows + (size_t)row * V224_ROWWORDS;
   unsigned meta = rowmeta[row];
   if (meta == V224_META_PORT) return (r[state >> 5] >> (state & 31)) & 1u;
+  if (meta & (1u << 16)) return lds8_get_decision(r, meta & 0xffu, state);
   return fused_get_decision(r, meta, state);
 }
 
@@ -249,9 +271,9 @@ __global__ void k_decodeword(const uint32_t *__restrict__ rows, const uint32_t *
 // first index holding the minimum (port.c:113-122: strict <, lowest index wins).
 // minval = min of the current buffer, already known from the last ACS launch's slot.
 __global__ __launch_bounds__(256) void k_argmin(const uint16_t *__restrict__ m, const V224Dev *ds,
-                                                unsigned slot, unsigned *out) {
+                                                unsigned pass, unsigned *out) {
   unsigned t = blockIdx.x * 256 + threadIdx.x;       // 2^20 threads x 8 states
-  unsigned minval = ds->slot[slot];
+  unsigned minval = input_min(ds, pass);
   uint4 v = reinterpret_cast<const uint4 *>(m)[t];
   const unsigned *w = reinterpret_cast<const unsigned *>(&v);
   unsigned best = 0xffffffffu;
@@ -290,10 +312,14 @@ __global__ __launch_bounds__(256) void k_export_row(const uint32_t *__restrict__
 }
 
 __global__ __launch_bounds__(256) void k_export_metrics(const uint16_t *__restrict__ m,
-                                                        const V224Dev *ds, unsigned slot,
+                                                        const V224Dev *ds, unsigned pass,
                                                         uint32_t *__restrict__ out) {
   unsigned t = blockIdx.x * 256 + threadIdx.x;       // 2^23 threads
-  out[t] = (unsigned)m[t] - ds->slot[slot];
+  out[t] = (unsigned)m[t] - input_min(ds, pass);
+}
+__global__ __launch_bounds__(256) void k_cur_min(const V224Dev *ds, unsigned pass, unsigned *out) {
+  unsigned v = input_min(ds, pass);
+  if (threadIdx.x == 0) *out = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -316,12 +342,12 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   }
   v = new V224();
   v->len = len;
-  v->engine = engine >= 0 ? engine : env_int("V224HIP_ENGINE", V224HIP_ENGINE_FUSED);
+  v->engine = engine >= 0 ? engine : env_int("V224HIP_ENGINE", V224HIP_ENGINE_LDS);
   v->K = k > 0 ? k : env_int("V224HIP_K", FUSED_DEFAULT_K);
   if (v->K < 1) v->K = 1;
   if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;
   v->dev = g_device >= 0 ? g_device : env_int("V224HIP_DEVICE", 0);
-  v->chunk = env_int("V224HIP_CHUNK", 1020);   // multiple of 2,3,4,5,6: no ragged pass per chunk
+  v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : 1020);   // whole passes per chunk
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
@@ -427,12 +453,15 @@ static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
   EvPair ev; const bool timed = prof_begin(v, &ev);
   while (done < nbits) {
     int k = 1;
-    if (v->engine == V224HIP_ENGINE_FUSED) {
-      k = v->K;
+    if (v->engine != V224HIP_ENGINE_SIMPLE) {
+      k = v->engine == V224HIP_ENGINE_LDS ? 8 : v->K;
       if (k > nbits - done) k = nbits - done;
       if (k > v->len - v->dp) k = v->len - v->dp;      // a pass never wraps the ring
     }
-    if (v->engine == V224HIP_ENGINE_FUSED) {
+    if (v->engine == V224HIP_ENGINE_LDS && k == 8) {
+      k_acs_lds8<<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
+                                         v->pass, v->rowmeta);
+    } else if (v->engine != V224HIP_ENGINE_SIMPLE) {
       if (fused_launch(k, v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
                        v->pass, v->rowmeta, v->st) != 0) {
         snprintf(g_err, sizeof g_err, "fused_launch(k=%d) failed", k);
@@ -493,7 +522,7 @@ extern "C" int v224hip_update_dev(void *p, const uint8_t *d_syms, int nbits) {
 static int best_state(V224 *v, unsigned *state) {
   unsigned *d = (unsigned *)v->dmisc;
   HIPCHK(hipMemsetAsync(d, 0xff, sizeof(unsigned), v->st));
-  k_argmin<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass % 3, d);
+  k_argmin<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, d);
   HIPCHK(hipMemcpyAsync(state, d, sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
   HIPCHK(hipStreamSynchronize(v->st));
   return 0;
@@ -559,8 +588,9 @@ static int metric_extreme(V224 *v, int want_max, long long *out) {
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned), v->st));
   if (want_max) k_max<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], d);
+  k_cur_min<<<1, 256, 0, v->st>>>(v->ds, v->pass, d + 1);
   HIPCHK(hipMemcpyAsync(&h[0], d, sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
-  HIPCHK(hipMemcpyAsync(&h[1], &v->ds->slot[v->pass % 3], sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipMemcpyAsync(&h[1], d + 1, sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
   HIPCHK(hipMemcpyAsync(&off, &v->ds->off, sizeof off, hipMemcpyDeviceToHost, v->st));
   HIPCHK(hipStreamSynchronize(v->st));
   *out = (long long)(want_max ? h[0] : h[1]) + off;
@@ -689,7 +719,7 @@ extern "C" int v224hip_export_metrics(void *p, uint32_t *out) {
   if (!v) return -1;
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipMalloc(&d, (size_t)V224_NSTATES * sizeof(uint32_t)));
-  k_export_metrics<<<V224_NSTATES / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass % 3, d);
+  k_export_metrics<<<V224_NSTATES / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, d);
   HIPCHK(hipMemcpyAsync(out, d, (size_t)V224_NSTATES * sizeof(uint32_t), hipMemcpyDeviceToHost, v->st));
   HIPCHK(hipStreamSynchronize(v->st));
   (void)hipFree(d);

@@ -183,3 +183,17 @@ def test_min_max_metric_track_port_scale(pkg):
         assert (d.min_metric(), d.max_metric()) == (lo, hi)
         d.close()
     o.close()
+
+
+# ---- engine LDS (8 steps per launch through LDS tiles) -----------------------------------------
+@pytest.mark.parametrize("name", _names())
+def test_framed_fixture_lds_engine(pkg, name):
+    test_framed_fixture(pkg, name, 2, 0)
+
+
+def test_stream_fixture_full_lds_engine(pkg):
+    test_stream_fixture_full(pkg, 2, 0)
+
+
+def test_seeded_stream_vs_oracle_lds_engine(pkg):
+    test_seeded_stream_vs_oracle(pkg, 2, 0)
