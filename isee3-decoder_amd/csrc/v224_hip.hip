@@ -459,7 +459,7 @@ static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
       if (k > v->len - v->dp) k = v->len - v->dp;      // a pass never wraps the ring
     }
     if (v->engine == V224HIP_ENGINE_LDS && k == 8) {
-      k_acs_lds8<<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
+      k_acs_lds8<0><<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
                                          v->pass, v->rowmeta);
     } else if (v->engine != V224HIP_ENGINE_SIMPLE) {
       if (fused_launch(k, v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,

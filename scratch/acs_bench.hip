@@ -34,6 +34,7 @@ static double run_store(int nlaunch, uint32_t *a, uint32_t *b, hipStream_t st) {
   go(100); hipStreamSynchronize(st); hipEventRecord(e0, st); go(nlaunch); hipEventRecord(e1, st); hipStreamSynchronize(st);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); return ms * 1e3 / nlaunch;
 }
+template <int ABL>
 static double run_lds8(int nlaunch, uint16_t *m0, uint16_t *m1, uint32_t *rows, int nrows, uint8_t *syms, V224Dev *ds,
                        uint32_t *rowmeta, hipStream_t st) {
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, st>>>(m0, 0, ds, rowmeta, nrows);
@@ -44,7 +45,7 @@ static double run_lds8(int nlaunch, uint16_t *m0, uint16_t *m1, uint32_t *rows, 
     for (int i = 0; i < n; i++) {
       unsigned pass = pass0 + i;
       int row0 = (int)((pass * 8) % (unsigned)(nrows - 8));
-      k_acs_lds8<<<512, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
+      k_acs_lds8<ABL><<<512, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
     }
   };
   go(200, 0); hipStreamSynchronize(st); hipEventRecord(a, st); go(nlaunch, 200); hipEventRecord(b, st); hipStreamSynchronize(st);
@@ -108,8 +109,8 @@ int main(int argc, char **argv) {
   }
   printf("store 16 MiB row-per-lane: %6.2f us | lane-contiguous: %6.2f us\n", run_store<0>(nlaunch, (uint32_t *)m0, (uint32_t *)m1, st), run_store<1>(nlaunch, (uint32_t *)m0, (uint32_t *)m1, st));
   for (int rep = 0; rep < 2; rep++) {
-    double t = run_lds8(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st);
-    printf("LDS8 : %7.2f us/launch  %6.3f us/bit\n", t, t / 8);
+#define L(ABL, what) printf("LDS8 PK=%d ABL=%2d %-30s: %7.2f us/launch\n", LDS8_PK, ABL, what, run_lds8<ABL>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
+    L(0, "full") L(14, "arith + LDS only") L(30, "arith + LDS, no min")
     double t5 = run<5, 0, 0, 0>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st);
     printf("K=5  : %7.2f us/launch  %6.3f us/bit\n", t5, t5 / 5);
   }

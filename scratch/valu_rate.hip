@@ -1,0 +1,61 @@
+// VALU issue-rate microbenchmark with inline asm (nothing for the compiler to fold)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define ITER 1000
+#define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+#define KERN(NAME, INSN)                                                                         \
+  __global__ __launch_bounds__(256) void NAME(unsigned *out, unsigned seed) {                    \
+    unsigned a[8], b = seed | 3, c = seed * 7 + 1;                                               \
+    for (int k = 0; k < 8; k++) a[k] = threadIdx.x * (k + 3) + seed;                            \
+    for (int i = 0; i < ITER; i++) {                                                             \
+      asm volatile(INSN("%0") INSN("%1") INSN("%2") INSN("%3") INSN("%4") INSN("%5") INSN("%6") INSN("%7") \
+                   INSN("%0") INSN("%1") INSN("%2") INSN("%3") INSN("%4") INSN("%5") INSN("%6") INSN("%7") \
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
+                   : "v"(b), "v"(c));                                                            \
+    }                                                                                            \
+    out[blockIdx.x * 256 + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7]; \
+  }
+#define I_ADD(r) "v_add_u32 " r ", " r ", %8\n"
+#define I_SUB(r) "v_sub_u32 " r ", " r ", %8\n"
+#define I_PKADD(r) "v_pk_add_u16 " r ", " r ", %8\n"
+#define I_PKSUB(r) "v_pk_sub_i16 " r ", " r ", %8\n"
+#define I_PKMIN(r) "v_pk_min_u16 " r ", " r ", %8\n"
+#define I_PKSHR(r) "v_pk_lshrrev_b16 " r ", 1, " r "\n"
+#define I_PKMAD(r) "v_pk_mad_u16 " r ", " r ", %8, %9\n"
+#define I_SHR(r) "v_lshrrev_b32 " r ", 1, " r "\n"
+#define I_AND(r) "v_and_b32 " r ", " r ", %8\n"
+#define I_BFI(r) "v_bfi_b32 " r ", %8, %9, " r "\n"
+#define I_ANDOR(r) "v_and_or_b32 " r ", " r ", %8, %9\n"
+#define I_LSHLOR(r) "v_lshl_or_b32 " r ", " r ", 1, %9\n"
+#define I_PERM(r) "v_perm_b32 " r ", " r ", %8, %9\n"
+#define I_ALIGN(r) "v_alignbit_b32 " r ", " r ", %8, 1\n"
+#define I_MIN(r) "v_min_u32 " r ", " r ", %8\n"
+#define I_ADD3(r) "v_add3_u32 " r ", " r ", %8, %9\n"
+#define I_FMA(r) "v_fma_f32 " r ", " r ", %8, %9\n"
+#define I_OR3(r) "v_or3_b32 " r ", " r ", %8, %9\n"
+#define I_CNDM(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n"
+#define I_MINU16(r) "v_min_u16 " r ", " r ", %8\n"
+KERN(k_add, I_ADD) KERN(k_sub, I_SUB) KERN(k_pkadd, I_PKADD) KERN(k_pksub, I_PKSUB) KERN(k_pkmin, I_PKMIN)
+KERN(k_pkshr, I_PKSHR) KERN(k_pkmad, I_PKMAD) KERN(k_shr, I_SHR) KERN(k_and, I_AND) KERN(k_bfi, I_BFI)
+KERN(k_andor, I_ANDOR) KERN(k_lshlor, I_LSHLOR) KERN(k_perm, I_PERM) KERN(k_align, I_ALIGN) KERN(k_min, I_MIN)
+KERN(k_add3, I_ADD3) KERN(k_fma, I_FMA) KERN(k_or3, I_OR3) KERN(k_minu16, I_MINU16)
+template <typename F> static void run(const char *name, F kern, unsigned *out) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  printf("%-14s", name);
+  for (int waves : {1, 2, 4, 8}) {
+    int blocks = 256 * waves;
+    kern<<<blocks, 256>>>(out, 1); hipDeviceSynchronize();
+    hipEventRecord(a); kern<<<blocks, 256>>>(out, 2); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    double n = (double)waves * ITER * 16;
+    printf("  w%d: %5.2f cyc", waves, ms * 1e6 / n * 2.4);
+  }
+  printf("   (cycles per wave-instruction per SIMD at 2.4 GHz)\n");
+}
+int main() {
+  unsigned *out; hipMalloc(&out, 256 * 8 * 256 * 4 * 4);
+#define R(n) run(#n, n, out);
+  R(k_add) R(k_sub) R(k_pkadd) R(k_pksub) R(k_pkmin) R(k_pkshr) R(k_pkmad) R(k_shr) R(k_and) R(k_bfi) R(k_andor)
+  R(k_lshlor) R(k_perm) R(k_align) R(k_min) R(k_add3) R(k_fma) R(k_or3) R(k_minu16)
+  return 0;
+}
