@@ -63,7 +63,8 @@ struct V224 {
   size_t dmisc_cap;
   int dp;                   // next row to write
   unsigned long long nsteps;// trellis steps since init
-  unsigned pass;            // ACS launches since init (slot rotation)
+  unsigned pass;            // ACS launches since init (minima ping-pong index)
+  bool min_valid;           // blkmin[pass & 1] describes the current metric buffer
   int chunk;                // stream chunk (bits)
   int profile;              // time every profile-th run of ACS launches (0 = off)
   unsigned long long launches_seen;
@@ -103,13 +104,18 @@ __global__ __launch_bounds__(256) void k_init(uint16_t *m, unsigned start, V224D
 }
 __global__ void k_init_start(uint16_t *m, unsigned start) { m[start] = (uint16_t)V224_BASE; }
 
+// wave64 minimum with DPP row operations (VALU only; __shfl_xor would be six ds_bpermute round trips)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned w = __shfl_xor(v, o, 64);
-    v = w < v ? w : v;
-  }
-  return v;
+#define V224_DPPMIN(ctrl, rowmask)                                                        \
+  { unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rowmask, 0xf, false); v = o < v ? o : v; }
+  V224_DPPMIN(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  V224_DPPMIN(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  V224_DPPMIN(0x141, 0xf)   // row_half_mirror
+  V224_DPPMIN(0x140, 0xf)   // row_mirror: every lane of a 16-lane row now holds the row minimum
+  V224_DPPMIN(0x142, 0xa)   // row_bcast15 into rows 1 and 3
+  V224_DPPMIN(0x143, 0xc)   // row_bcast31 into rows 2 and 3: lane 63 holds the wave minimum
+#undef V224_DPPMIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // minimum of the metrics this launch reads = min over the previous launch's per-workgroup minima.
@@ -317,6 +323,26 @@ __global__ __launch_bounds__(256) void k_export_metrics(const uint16_t *__restri
   unsigned t = blockIdx.x * 256 + threadIdx.x;       // 2^23 threads
   out[t] = (unsigned)m[t] - input_min(ds, pass);
 }
+// recompute the per-workgroup minima of the current metric buffer (only needed when a launch that
+// skipped publishing is followed by something that wants them: a ring-wrap remainder pass)
+__global__ __launch_bounds__(256) void k_publish_min(const uint16_t *__restrict__ m, V224Dev *ds, unsigned pass) {
+  unsigned mn = 0xffffffffu;
+  for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < V224_NSTATES / 8; t += gridDim.x * 256) {
+    uint4 v = reinterpret_cast<const uint4 *>(m)[t];
+    const unsigned *w = reinterpret_cast<const unsigned *>(&v);
+#pragma unroll
+    for (int n = 0; n < 8; n++) { unsigned x = (w[n >> 1] >> (16 * (n & 1))) & 0xffffu; mn = x < mn ? x : mn; }
+  }
+  mn = wave_min_u32(mn);
+  __shared__ unsigned s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = s[0] < s[1] ? s[0] : s[1], b = s[2] < s[3] ? s[2] : s[3];
+    ds->blkmin[pass & 1][blockIdx.x] = a < b ? a : b;
+    if (blockIdx.x == 0) ds->nmin[pass & 1] = gridDim.x;
+  }
+}
 __global__ __launch_bounds__(256) void k_cur_min(const V224Dev *ds, unsigned pass, unsigned *out) {
   unsigned v = input_min(ds, pass);
   if (threadIdx.x == 0) *out = v;
@@ -396,7 +422,7 @@ extern "C" int init_viterbi224(void *p, int starting_state) {
   if (!v) return -1;
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
-  v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0;
+  v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0; v->min_valid = true;
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
   k_init_start<<<1, 1, 0, v->st>>>(v->m[0], (unsigned)starting_state & V224_SMASK);
   HIPCHK(hipGetLastError());
@@ -445,6 +471,12 @@ static void prof_end(V224 *v, EvPair *e, unsigned steps, unsigned launches) {
 
 // ---- ACS dispatch --------------------------------------------------------------------------
 // Enqueue nbits trellis steps reading symbols from device memory (2 per step).
+static void ensure_min_valid(V224 *v) {
+  if (v->min_valid) return;
+  k_publish_min<<<512, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass);
+  v->min_valid = true;
+}
+
 static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
   int done = 0;
   unsigned nlaunch = 0;
@@ -459,15 +491,25 @@ static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
       if (k > v->len - v->dp) k = v->len - v->dp;      // a pass never wraps the ring
     }
     if (v->engine == V224HIP_ENGINE_LDS && k == 8) {
-      k_acs_lds8<0><<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
-                                         v->pass, v->rowmeta);
+      // minimum tracking is split over two launches where possible: (adjust, no publish) then
+      // (no adjust, publish).  The last launch of a run always publishes, so every other kernel
+      // (remainder passes, traceback helpers, the next call) finds valid minima.
+      const bool last = (nbits - done - 8) < 8;      // next pass is a remainder pass or none
+      const bool tin = v->min_valid, tout = !tin || last;
+#define LDS8_GO(TIN, TOUT) k_acs_lds8<0, TIN, TOUT><<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, \
+                                                   d_syms + 2 * done, v->ds, v->pass, v->rowmeta)
+      if (tin && tout) LDS8_GO(true, true); else if (tin) LDS8_GO(true, false); else LDS8_GO(false, true);
+#undef LDS8_GO
+      v->min_valid = tout;
     } else if (v->engine != V224HIP_ENGINE_SIMPLE) {
+      ensure_min_valid(v);
       if (fused_launch(k, v->m[v->cur], v->m[v->cur ^ 1], v->rows, v->dp, d_syms + 2 * done, v->ds,
                        v->pass, v->rowmeta, v->st) != 0) {
         snprintf(g_err, sizeof g_err, "fused_launch(k=%d) failed", k);
         return -1;
       }
     } else {
+      ensure_min_valid(v);
       k_acs_simple<<<V224_NSTATES / 32 / 256, 256, 0, v->st>>>(
           v->m[v->cur], v->m[v->cur ^ 1], v->rows + (size_t)v->dp * V224_ROWWORDS,
           d_syms + 2 * done, v->ds, v->pass, v->rowmeta, v->dp);
@@ -521,6 +563,7 @@ extern "C" int v224hip_update_dev(void *p, const uint8_t *d_syms, int nbits) {
 
 static int best_state(V224 *v, unsigned *state) {
   unsigned *d = (unsigned *)v->dmisc;
+  ensure_min_valid(v);
   HIPCHK(hipMemsetAsync(d, 0xff, sizeof(unsigned), v->st));
   k_argmin<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, d);
   HIPCHK(hipMemcpyAsync(state, d, sizeof(unsigned), hipMemcpyDeviceToHost, v->st));
@@ -586,6 +629,7 @@ static int metric_extreme(V224 *v, int want_max, long long *out) {
   unsigned *d = (unsigned *)(v->dmisc + 256);
   unsigned h[2]; long long off;
   HIPCHK(hipSetDevice(v->dev));
+  ensure_min_valid(v);
   HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned), v->st));
   if (want_max) k_max<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], d);
   k_cur_min<<<1, 256, 0, v->st>>>(v->ds, v->pass, d + 1);
@@ -719,6 +763,7 @@ extern "C" int v224hip_export_metrics(void *p, uint32_t *out) {
   if (!v) return -1;
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipMalloc(&d, (size_t)V224_NSTATES * sizeof(uint32_t)));
+  ensure_min_valid(v);
   k_export_metrics<<<V224_NSTATES / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, d);
   HIPCHK(hipMemcpyAsync(out, d, (size_t)V224_NSTATES * sizeof(uint32_t), hipMemcpyDeviceToHost, v->st));
   HIPCHK(hipStreamSynchronize(v->st));
