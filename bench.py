@@ -69,6 +69,48 @@ def cpu_baseline(nbits_sample):
             "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nbits_sample, what, dt)}
 
 
+def chain_workload(a, rank, world, local, dist, torch, pkg):
+    """BASELINE.json configs[2]/[3]: full pmdemod | symdemod | vdecode chain on synthetic int16 IQ,
+    one independent capture per GPU (bin/isee3chain = the three C pipe stages as threads of one
+    process; the capture is piped in from host memory, so PCIe and pipe copies are inside the time)."""
+    import subprocess
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+    harness = import_module("isee3_decoder_amd.harness")
+    fs = float(a.chain_rate)
+    iq, sent = synth.iq_capture(3 + rank, fs, a.chain_seconds)
+    data = iq.tobytes()
+    exe = pkg.cli_path("isee3chain")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=str(local), ROCR_VISIBLE_DEVICES="")
+    env.pop("ROCR_VISIBLE_DEVICES")
+    args = [exe, "-r", str(int(fs)), "-b", str(a.chain_bin), "-c", "1024", "-d", str(a.delay)]
+    out = {}
+
+    def step():
+        p = subprocess.run(args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        if p.returncode != 0:
+            raise SystemExit("isee3chain failed: " + p.stderr.decode()[-500:])
+        out["bits"] = p.stdout
+
+    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
+    dt = harness.timed_steps(step, a.steps, a.warmup, fence)
+    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, "cuda")
+    got = np.frombuffer(out["bits"], np.uint8) - ord("0")
+    s = "".join(map(str, sent))
+    ok = len(got) > 1500 and "".join(map(str, got[300:1300])) in s
+    if rank == 0:
+        nsamp = len(iq) // 2
+        print(json.dumps({
+            "metric": "end-to-end IQ Msamples/s", "value": round(nsamp * world * a.steps / dt / 1e6, 3),
+            "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic",
+            "config": {"workload": "pmdemod|symdemod|vdecode on %g s of %g kS/s int16 IQ, %g Hz bins, 1024 sym/s "
+                                   "Manchester, one capture per GPU (host -> pipe -> GPU included)"
+                                   % (a.chain_seconds, fs / 1e3, a.chain_bin), "decoded_bits": int(len(got))},
+            "roofline": None, "check": {"decoded_run_found_in_sent_stream": bool(ok)}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +125,10 @@ def main():
                     help="independent streams decoded concurrently on each GPU (own HIP streams)")
     ap.add_argument("--cpu-bits", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=["viterbi", "chain"], default="viterbi")
+    ap.add_argument("--chain-seconds", type=float, default=60.0)
+    ap.add_argument("--chain-rate", type=float, default=250000.0)
+    ap.add_argument("--chain-bin", type=float, default=1.0)
     a = ap.parse_args()
 
     import torch
@@ -98,6 +144,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     pkg = load_pkg()
+    if a.workload == "chain":
+        chain_workload(a, rank, world, local, dist, torch, pkg)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     pkg.v224_lib().v224hip_set_device(local)
     from importlib import import_module
     synth = import_module("isee3_decoder_amd.synth")

@@ -43,3 +43,46 @@ def coded_stream(seed, nbits, ebn0_db=3.0, amplitude=24.0, noise_block_pct=1.0):
     sig[mask] = 0
     x = 128 + sig + rng.normal(0, sigma, 2 * nbits).astype(np.float32)
     return np.clip(np.rint(x), 0, 255).astype(np.uint8), bits, mask
+
+
+SYNCWORD = 0x12fc819fbe      # reference framer.c:18 / decode.c:24
+ACTUALCLOCK = 1024.545058    # reference symdemod.c:18
+
+
+def telemetry_bits(seed, nbits):
+    """1024-bit frames whose last 40 bits are the sync word (reference framer.c:12-18,69)."""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, nbits, dtype=np.uint8)
+    sync = np.array([(SYNCWORD >> (39 - i)) & 1 for i in range(40)], dtype=np.uint8)
+    for f in range(0, nbits - 1023, 1024):
+        bits[f + 984:f + 1024] = sync
+    return bits
+
+
+def iq_capture(seed, samprate, seconds, fc_hz=12345.678, beta=1.1, symrate=ACTUALCLOCK, amp=3000.0,
+               cn0_dbhz=45.0, chunk=1 << 22):
+    """Synthetic PM capture: int16 interleaved I,Q of
+    A*exp(j(2 pi fc t + phi0 + beta*m(t))) + complex AWGN, m(t) = Manchester of the r=1/2 encoded
+    telemetry (first half -, second half + for symbol 1: reference symdemod.c:227-235); modulation
+    index 1.1 rad (pmdemod.c:83).  A = 3000 keeps 5 sigma of the 45 dB-Hz noise inside int16.
+    Returns (iq int16[2n], sent bits)."""
+    n = int(samprate * seconds)
+    nsym = int(seconds * symrate) + 4
+    bits = telemetry_bits(seed, nsym // 2 + 2)
+    sy = encode_bits(bits)[:nsym].astype(np.int8) * 2 - 1
+    rng = np.random.default_rng(seed + 7)
+    phi0 = rng.random() * 2 * np.pi
+    sigma = amp * np.sqrt(samprate / (2.0 * 10 ** (cn0_dbhz / 10.0)))
+    out = np.empty(2 * n, dtype=np.int16)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        i = np.arange(s, e, dtype=np.float64)
+        ph = i * (symrate / samprate)
+        k = ph.astype(np.int64)
+        m = np.where(ph - k < 0.5, -1.0, 1.0) * sy[k]
+        th = np.mod(i * (2 * np.pi * fc_hz / samprate), 2 * np.pi) + phi0 + beta * m
+        x = amp * np.cos(th) + rng.normal(0, sigma, e - s)
+        y = amp * np.sin(th) + rng.normal(0, sigma, e - s)
+        out[2 * s:2 * e:2] = np.clip(np.rint(x), -32767, 32767).astype(np.int16)
+        out[2 * s + 1:2 * e:2] = np.clip(np.rint(y), -32767, 32767).astype(np.int16)
+    return out, bits

@@ -190,3 +190,14 @@ def test_full_chain_cli(pkg):
     s = "".join(map(str, sent))
     g = "".join(map(str, got[100:1100]))
     assert g in s, "decoded bit run not found in the transmitted stream"
+
+
+def test_in_process_chain_equals_three_stage_pipeline(pkg):
+    """bin/isee3chain (the three stages as threads of one process) == pmdemod | symdemod | vdecode"""
+    fs = 32768.0
+    iq, sent = orc.gen_iq(89, fs, 6.0, fc_hz=-3456.7, amp=3000.0, cn0_dbhz=48.0)
+    bb = _run(pkg.cli_path("pmdemod"), ["-q", "-r", str(fs), "-b", "1"], iq.tobytes())
+    sy = _run(pkg.cli_path("symdemod"), ["-q", "-r", str(int(fs)), "-c", "1024"], bb)
+    bits = _run(pkg.cli_path("vdecode"), ["-q"], sy)
+    chain = _run(pkg.cli_path("isee3chain"), ["-r", str(int(fs)), "-b", "1", "-c", "1024"], iq.tobytes())
+    assert chain == bits and len(bits) > 2000
