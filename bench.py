@@ -200,6 +200,13 @@ def main():
         avg_ms = ms / launches if launches else float("nan")
         steps_per_launch = steps_timed / launches if launches else 0
         ach = ALG_BYTES_PER_STEP * steps_per_launch / (avg_ms * 1e-3) / 1e9 if launches else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        kern = {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8"}[eng]
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == kern:       # PMC passes cannot share a run with the timing: committed constant
+                traffic = tj["hbm_bytes_per_launch"]
         res = {
             "metric": "Viterbi K=24 Msymbols/s",
             "value": round(total_syms / dt / 1e6, 4), "unit": "Msymbols/s",
@@ -215,8 +222,9 @@ def main():
                        "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
-                         "traffic": None,
-                         "kernel": {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8"}[eng],
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_STEP * steps_per_launch),
+                         "kernel": kern,
                          "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "launches_timed": launches},
             "check": {"ber_clean": ber, "bits": int(clean.sum())},

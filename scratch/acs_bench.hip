@@ -34,7 +34,7 @@ static double run_store(int nlaunch, uint32_t *a, uint32_t *b, hipStream_t st) {
   go(100); hipStreamSynchronize(st); hipEventRecord(e0, st); go(nlaunch); hipEventRecord(e1, st); hipStreamSynchronize(st);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); return ms * 1e3 / nlaunch;
 }
-template <int ABL, bool ALT = false>
+template <int ABL, bool ALT = false, int TILES = 1>
 static double run_lds8(int nlaunch, uint16_t *m0, uint16_t *m1, uint32_t *rows, int nrows, uint8_t *syms, V224Dev *ds,
                        uint32_t *rowmeta, hipStream_t st) {
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, st>>>(m0, 0, ds, rowmeta, nrows);
@@ -45,9 +45,9 @@ static double run_lds8(int nlaunch, uint16_t *m0, uint16_t *m1, uint32_t *rows, 
     for (int i = 0; i < n; i++) {
       unsigned pass = pass0 + i;
       int row0 = (int)((pass * 8) % (unsigned)(nrows - 8));
-      if (!ALT) k_acs_lds8<ABL><<<512, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
-      else if (pass & 1) k_acs_lds8<ABL, false, true><<<512, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
-      else k_acs_lds8<ABL, true, false><<<512, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
+      if (!ALT) k_acs_lds8<ABL, true, true, TILES><<<512 / TILES, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
+      else if (pass & 1) k_acs_lds8<ABL, false, true, TILES><<<512 / TILES, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
+      else k_acs_lds8<ABL, true, false, TILES><<<512 / TILES, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
     }
   };
   go(200, 0); hipStreamSynchronize(st); hipEventRecord(a, st); go(nlaunch, 200); hipEventRecord(b, st); hipStreamSynchronize(st);
@@ -138,6 +138,7 @@ int main(int argc, char **argv) {
 #define L(ABL, what) printf("LDS8 PK=%d ABL=%2d %-30s: %7.2f us/launch\n", LDS8_PK, ABL, what, run_lds8<ABL>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     L(0, "full") L(14, "arith + LDS only") L(30, "arith + LDS, no min")
     printf("LDS8 via hipGraph (128 launches per graph): %7.2f us/launch\n", run_lds8_graph(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
+    printf("LDS8 2 tiles per workgroup: %7.2f us/launch, alternating min: %7.2f\n", run_lds8<0, false, 2>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st), run_lds8<0, true, 2>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     printf("LDS8 alternating min tracking: %7.2f us/launch\n", run_lds8<0, true>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     double t5 = run<5, 0, 0, 0>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st);
     printf("K=5  : %7.2f us/launch  %6.3f us/bit\n", t5, t5 / 5);
