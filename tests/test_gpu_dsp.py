@@ -201,3 +201,22 @@ def test_in_process_chain_equals_three_stage_pipeline(pkg):
     bits = _run(pkg.cli_path("vdecode"), ["-q"], sy)
     chain = _run(pkg.cli_path("isee3chain"), ["-r", str(int(fs)), "-b", "1", "-c", "1024"], iq.tobytes())
     assert chain == bits and len(bits) > 2000
+
+
+def test_stress_10msps_block_and_window(pkg):
+    """BASELINE configs[4] shapes: 10 MS/s, 1 Hz bins => N = 2^23 FFT blocks, 9 760 samples per symbol
+    (timesearch over 9 761 offsets).  One pmdemod block and one symdemod window against the oracle."""
+    fs = 10_000_000.0
+    N = 1 << 23
+    iq, _ = orc.gen_iq(91, fs, N / fs + 1e-4, fc_hz=2_345_678.9, amp=3000.0, cn0_dbhz=45.0 + 10 * math.log10(fs / 250000.0))
+    iq = iq[:2 * N]
+    ref_out, ref_pre, ref_rep, n2 = orc.pmdemod(iq, samprate=fs, binsize=1.0)
+    assert n2 == N and len(ref_rep) == 1
+    out, pre, reps, _ = _gpu_pmdemod(pkg, iq, fs, 1.0)
+    w = _check_pm(out, pre, reps, N, ref_out, ref_pre, ref_rep)
+    print("N=2^23 worst relative deviation %.3g" % w)
+    # symdemod at 10 MS/s: window 0.2 s (204 symbols), Symbolsamples 9760.43
+    bb, _ = orc.gen_baseband(92, fs, 0.45, amp=600.0, noise_sigma=4000.0)
+    sy_ref, ph_ref, en_ref = orc.symdemod(bb, samprate=int(fs), c_opt="1024", window=0.2)
+    out = _run(pkg.cli_path("symdemod"), ["-q", "-r", str(int(fs)), "-c", "1024", "-w", "0.2"], bb.tobytes())
+    assert out == sy_ref.tobytes() and len(out) >= 204
