@@ -14,6 +14,8 @@ reference's own code run here:
   * vdecode_cli.npz      oracle/_ref/vdecode_port_ref (vdecode.c unmodified) stdout, incl. a forced
                          phase flip, the -p start phase and -F.
   * symdemod_cli.npz     oracle/_ref/symdemod_ref (symdemod.c unmodified) stdout.
+  * decode_cli.npz       oracle/_ref/decode_port_ref (decode.c -V unmodified, port decoder) stdout: frame-sync
+                         correlator + init(0x819fbe)/update(1024)/chainback per frame.
   * pmdemod_oracle.npz   NOT from the reference (FFTW3 absent => pmdemod.c cannot be built): outputs
                          of this repo's restatement, kept only as a regression anchor.  UNPINNED.
 Fixtures hold data only: inputs (or the seed + sha256 of a regenerable input) and expected outputs.
@@ -168,6 +170,16 @@ def make_vdecode():
     np.savez_compressed(os.path.join(HERE, "vdecode_cli.npz"), **flat)
 
 
+def make_decode():
+    """the reference's framed driver decode.c (Fano off: -V) on the port decoder."""
+    sy, _ = _tlm_symbols(601, 4 * 1024 + 200, 5.0)
+    out = orc.ref_cli("decode_port_ref", ["-V"], sy.tobytes())
+    np.savez_compressed(os.path.join(HERE, "decode_cli.npz"), syms=sy, stdout=np.frombuffer(out, dtype=np.uint8),
+                        args=np.array(["-V"]))
+    print("decode", len(sy), "symbols ->", len(out), "bytes of frame dump")
+    print(out.decode(errors="replace")[:600])
+
+
 def make_symdemod():
     cases = [
         # name, args, generator kwargs
@@ -226,7 +238,7 @@ def make_pmdemod():
 
 
 ALL = dict(framed=make_framed, stream=make_stream, vdecode=make_vdecode, symdemod=make_symdemod,
-           pmdemod=make_pmdemod)
+           pmdemod=make_pmdemod, decode=make_decode)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

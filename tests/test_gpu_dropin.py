@@ -39,3 +39,17 @@ def test_reference_vtest224_source_on_hip_library():
     m = re.search(rb"BER (\d+)/(\d+).*FER (\d+)/(\d+)", p.stdout)
     assert m, p.stdout
     assert int(m.group(1)) == 0 and int(m.group(2)) == 3 * 512 and int(m.group(3)) == 0
+
+
+def test_reference_decode_source_on_hip_library():
+    """decode.c -V (frame sync, init(sync state) / update(1024) / chainback per frame,
+    hex frame dump) unmodified on the HIP library == the same program on viterbi224_port.c."""
+    z = np.load(os.path.join(orc.GOLDEN, "decode_cli.npz"))
+    p = subprocess.run([_exe("decode_hiplink"), "-V"], input=z["syms"].tobytes(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    def body(b):        # drop the banner lines, which start with argv[0]
+        return [l for l in b.split(b"\n") if b"_ref:" not in l and b"_hiplink:" not in l]
+    got, want = body(p.stdout), body(z["stdout"].tobytes())
+    assert got == want
+    assert any(l.endswith(b"12 fc 81 9f be") for l in got) and sum(l.startswith(b"Frame ") for l in got) >= 3
