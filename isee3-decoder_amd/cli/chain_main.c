@@ -1,125 +1,34 @@
-/* isee3chain -- pmdemod | symdemod | vdecode in ONE process: the three reference pipe stages
- * (pmdemod.c, symdemod.c, vdecode.c) run as threads of one program connected by pipe(2), so they
- * share one HIP context and one GPU instead of paying three process start-ups.  Each stage is
- * exactly the code of the stand-alone binary (the cli/ *_core.c files); stdin = int16 I,Q pairs, stdout = ASCII
- * '0'/'1'.  Options: the union of the stages' options that matter for a chain:
+/* isee3chain -- pmdemod | symdemod | vdecode in one process (see chain_core.c / include/isee3_chain.h).
+ * stdin = int16 I,Q pairs, stdout = ASCII '0'/'1'.  Options:
  *     -r Hz  sample rate (pmdemod -r, symdemod -r)        -b Hz  FFT bin size (pmdemod -b)
  *     -c Hz  symbol rate (symdemod -c)                    -d n   decode delay (vdecode -d)
- *     -W Hz / -S Hz / -f  pmdemod search width / start / flip          -v  keep the stages' status lines
- */
-#define _GNU_SOURCE
-#include <fcntl.h>
+ *     -W Hz / -S Hz / -f  pmdemod search width / start / flip          -v  keep the stages' status lines */
 #include <locale.h>
-#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include <string.h>
 #include <unistd.h>
-#include "pmdemod_core.h"
-#include "symdemod_core.h"
-#include "vdecode_core.h"
-#include "../../include/isee3_dsp_hip.h"
-#include "../../include/viterbi224_hip.h"
-
-/* ---- engines (same bindings as the stand-alone mains) ---- */
-static void *pm_create(int n) { return pmd_create(n); }
-static int pm_dechirp(void *h, const double *t) { return pmd_set_dechirp(h, t); }
-static int pm_load(void *h, const int16_t *iq, int flip) { return pmd_load(h, iq, 0, flip); }
-static int pm_peak(void *h, int a, int b, pmdemod_peak *o) {
-  pmd_peak p;
-  if (pmd_fft_peak(h, a, b, &p) != 0) return -1;
-  o->peak = p.peak; o->maxenergy = p.maxenergy; o->peak_re = p.peak_re; o->peak_im = p.peak_im;
-  o->next_re = p.next_re; o->next_im = p.next_im; o->prev_re = p.prev_re; o->prev_im = p.prev_im;
-  return 0;
-}
-static int pm_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) {
-  pmd_mix m;
-  if (pmd_mix_quantise(h, cstep, &m, out16, NULL, 0) != 0) return -1;
-  r->dc_re = m.dc_re; r->dc_im = m.dc_im; r->amplitude = m.amplitude; r->diffsumsq = m.diffsumsq;
-  return 0;
-}
-static void pm_destroy(void *h) { pmd_destroy(h); }
-
-static void *sy_create(int n) { return symd_create(n); }
-static int sy_load(void *h, const int16_t *s, int n) { return symd_load(h, s, n, 0); }
-static int sy_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) { return symd_timesearch(h, lo, sw, sc, ns, noff, en); }
-static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o, double *es) { return symd_demod(h, e, sc, ns, g, o, 0, es); }
-static void sy_destroy(void *h) { symd_destroy(h); }
-
-static int g_chunk = 1024;
-static void *vd_create(int len) { void *h = create_viterbi224(len); if (h) v224hip_set_option(h, "chunk", g_chunk); return h; }
-static int vd_init(void *h, int s) { return init_viterbi224(h, s); }
-static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) { return v224hip_stream_decode(h, s, n, d, o); }
-static void vd_destroy(void *h) { delete_viterbi224(h); }
-
-typedef struct { pmdemod_opts o; FILE *in, *out; int rc; } pm_arg;
-typedef struct { symdemod_opts o; int fd_in; FILE *out; int rc; } sy_arg;
-typedef struct { vdecode_opts o; int fd_in; int rc; } vd_arg;
-
-static void *pm_thread(void *p) {
-  pm_arg *a = p;
-  pmdemod_engine e = { pm_create, pm_dechirp, pm_load, pm_peak, pm_mix, pm_destroy };
-  a->rc = pmdemod_run(&a->o, &e, a->in, a->out, stderr, NULL, 0, NULL);
-  fclose(a->out);
-  return NULL;
-}
-static void *sy_thread(void *p) {
-  sy_arg *a = p;
-  symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy };
-  a->rc = symdemod_run(&a->o, &e, a->fd_in, a->out, stderr);
-  fclose(a->out);
-  close(a->fd_in);
-  return NULL;
-}
-static void *vd_thread(void *p) {
-  vd_arg *a = p;
-  vdecode_result r;
-  vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk };
-  a->rc = vdecode_run(&a->o, &e, a->fd_in, stdout, stderr, &r);
-  close(a->fd_in);
-  return NULL;
-}
+#include "../../include/isee3_chain.h"
 
 int main(int argc, char **argv) {
-  pm_arg pa; sy_arg sa; vd_arg va;
-  int c, verbose = 0, p1[2], p2[2];
+  isee3_chain_opts o;
+  int c;
   const char *lang = getenv("LANG");
   setlocale(LC_ALL, lang ? lang : "en_US.utf8");
-  pmdemod_default_opts(&pa.o); symdemod_default_opts(&sa.o); vdecode_default_opts(&va.o);
-  pa.o.argv0 = "isee3chain/pmdemod"; sa.o.argv0 = "isee3chain/symdemod"; va.o.argv0 = "isee3chain/vdecode";
+  isee3_chain_default_opts(&o);
   while ((c = getopt(argc, argv, "r:b:c:d:W:S:fv")) != -1) {
     switch (c) {
-    case 'r': pa.o.samprate = atof(optarg); sa.o.samprate = atoi(optarg); break;
-    case 'b': pa.o.binsize = atof(optarg); break;
-    case 'c': { char *av[3] = { "symdemod", "-c", optarg }; int keep = optind; symdemod_opts t; symdemod_parse_args(&t, 3, av);
-                sa.o.symrate = t.symrate; sa.o.symbolclocks = t.symbolclocks; optind = keep; } break;
-    case 'd': va.o.decode_delay = atoi(optarg); break;
-    case 'W': pa.o.search_width = atof(optarg); break;
-    case 'S': pa.o.search_freq = atof(optarg); break;
-    case 'f': pa.o.flip = 1; break;
-    case 'v': verbose = 1; break;
+    case 'r': o.samprate = atof(optarg); break;
+    case 'b': o.binsize = atof(optarg); break;
+    case 'c': o.symrate = optarg; break;
+    case 'd': o.decode_delay = atoi(optarg); break;
+    case 'W': o.search_width = atof(optarg); break;
+    case 'S': o.search_freq = atof(optarg); break;
+    case 'f': o.flip = 1; break;
+    case 'v': o.verbose = 1; break;
     default: fprintf(stderr, "usage: isee3chain [-r Hz] [-b Hz] [-c Hz] [-d n] [-W Hz] [-S Hz] [-f] [-v] < iq > bits\n"); return 1;
     }
   }
-  pa.o.quiet = sa.o.quiet = va.o.quiet = !verbose;
-  if (getenv("V224HIP_CHUNK")) g_chunk = atoi(getenv("V224HIP_CHUNK"));
-  if (g_chunk < 8) g_chunk = 1024;
-  if (pipe(p1) || pipe(p2)) { perror("pipe"); return 2; }
-#ifdef F_SETPIPE_SZ
-  fcntl(p1[1], F_SETPIPE_SZ, 1 << 20); fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);
-#endif
-  pa.in = stdin; pa.out = fdopen(p1[1], "w");
-  sa.fd_in = p1[0]; sa.out = fdopen(p2[1], "w");
-  va.fd_in = p2[0];
-  pthread_t t1, t2, t3;
-  pthread_create(&t1, NULL, pm_thread, &pa);
-  pthread_create(&t2, NULL, sy_thread, &sa);
-  pthread_create(&t3, NULL, vd_thread, &va);
-  pthread_join(t1, NULL); pthread_join(t2, NULL); pthread_join(t3, NULL);
-  if (pa.rc || sa.rc || va.rc) {
-    fprintf(stderr, "isee3chain: stage failed (pmdemod %d, symdemod %d, vdecode %d): %s / %s\n", pa.rc, sa.rc, va.rc,
-            isee3dsp_last_error(), v224hip_last_error());
-    return 2;
-  }
-  return 0;
+  int rc = isee3_chain_run_fd(&o, 0, 1);
+  if (rc) fprintf(stderr, "isee3chain: %s\n", isee3_chain_last_error());
+  return rc;
 }
