@@ -399,3 +399,56 @@ def cli_path(name):
     if not os.path.exists(p):
         raise NativeLibraryMissing("%s not built" % p)
     return p
+
+
+# ------------------------------------------------------------------------------------------------
+# libisee3chain.so : pmdemod | symdemod | vdecode on memory buffers (include/isee3_chain.h)
+# ------------------------------------------------------------------------------------------------
+CHAIN_SYMBOLS = ["isee3_chain_default_opts", "isee3_chain_run_mem", "isee3_chain_run_fd", "isee3_chain_last_error"]
+
+
+class ChainOpts(C.Structure):
+    _fields_ = [("samprate", C.c_double), ("binsize", C.c_double), ("search_freq", C.c_double),
+                ("search_width", C.c_double), ("flip", C.c_int), ("symrate", C.c_char_p),
+                ("decode_delay", C.c_int), ("verbose", C.c_int)]
+
+
+_chain = None
+
+
+def chain_lib():
+    global _chain
+    if _chain is not None:
+        return _chain
+    path = lib_path("libisee3chain.so")
+    if not os.path.exists(path):
+        raise NativeLibraryMissing("%s not built (no CPU fallback)" % path)
+    dsp_lib()
+    v224_lib()
+    L = C.CDLL(path)
+    L.isee3_chain_default_opts.argtypes = [C.POINTER(ChainOpts)]
+    L.isee3_chain_run_mem.argtypes = [C.POINTER(ChainOpts), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t)]
+    L.isee3_chain_run_fd.argtypes = [C.POINTER(ChainOpts), C.c_int, C.c_int]
+    L.isee3_chain_last_error.restype = C.c_char_p
+    _chain = L
+    return L
+
+
+def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=200, flip=False,
+              search_freq=0.0, search_width=0.0):
+    """int16 interleaved IQ (numpy) -> decoded bits as bytes of '0'/'1' (whole chain on the GPU)."""
+    L = chain_lib()
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    o = ChainOpts()
+    L.isee3_chain_default_opts(C.byref(o))
+    o.samprate, o.binsize, o.decode_delay, o.flip = samprate, binsize, decode_delay, int(flip)
+    o.search_freq, o.search_width = search_freq, search_width
+    o.symrate = None if symrate is None else str(symrate).encode()
+    cap = int(len(iq) / 2 / samprate * 1100) + 4096
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    rc = L.isee3_chain_run_mem(C.byref(o), iq.ctypes.data, len(iq) // 2, out, cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("isee3_chain_run_mem: " + (L.isee3_chain_last_error() or b"").decode())
+    return out.raw[:n.value]

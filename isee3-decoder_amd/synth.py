@@ -64,8 +64,11 @@ def iq_capture(seed, samprate, seconds, fc_hz=12345.678, beta=1.1, symrate=ACTUA
     """Synthetic PM capture: int16 interleaved I,Q of
     A*exp(j(2 pi fc t + phi0 + beta*m(t))) + complex AWGN, m(t) = Manchester of the r=1/2 encoded
     telemetry (first half -, second half + for symbol 1: reference symdemod.c:227-235); modulation
-    index 1.1 rad (pmdemod.c:83).  A = 3000 keeps 5 sigma of the 45 dB-Hz noise inside int16.
+    index 1.1 rad (pmdemod.c:83).  A = 3000 keeps 5 sigma of the 45 dB-Hz noise inside int16 at
+    250 kS/s; amp=None picks A so that the per-component noise sigma is 6000 at any sample rate.
     Returns (iq int16[2n], sent bits)."""
+    if amp is None:
+        amp = 6000.0 / np.sqrt(samprate / (2.0 * 10 ** (cn0_dbhz / 10.0)))
     n = int(samprate * seconds)
     nsym = int(seconds * symrate) + 4
     bits = telemetry_bits(seed, nsym // 2 + 2)

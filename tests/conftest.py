@@ -21,7 +21,8 @@ def _ensure_built():
     import subprocess
     pk = os.path.join(ROOT, "isee3-decoder_amd")
     need = [os.path.join(pk, "lib", "libviterbi224_hip.so"), os.path.join(pk, "lib", "libisee3dsp_hip.so"),
-            os.path.join(pk, "bin", "vdecode"), os.path.join(pk, "bin", "isee3chain")]
+            os.path.join(pk, "bin", "vdecode"), os.path.join(pk, "bin", "isee3chain"),
+            os.path.join(pk, "lib", "libisee3chain.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.run(["make", "-s", "-C", pk, "all"], check=True)
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):

@@ -65,3 +65,15 @@ def test_cli_binaries_built():
     pkg = load_pkg()
     for exe in ("vdecode", "symdemod", "pmdemod"):
         assert os.access(pkg.cli_path(exe), os.X_OK)
+
+
+def test_chain_header_vs_library():
+    pkg = load_pkg()
+    so = pkg.lib_path("libisee3chain.so")
+    assert os.path.exists(so)
+    L = C.CDLL(so)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "isee3_chain.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(isee3_chain_[a-z0-9_]+)\s*\(", txt)))
+    assert names == sorted(pkg.CHAIN_SYMBOLS)
+    for n in names:
+        assert hasattr(L, n)

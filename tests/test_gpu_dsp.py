@@ -201,6 +201,9 @@ def test_in_process_chain_equals_three_stage_pipeline(pkg):
     bits = _run(pkg.cli_path("vdecode"), ["-q"], sy)
     chain = _run(pkg.cli_path("isee3chain"), ["-r", str(int(fs)), "-b", "1", "-c", "1024"], iq.tobytes())
     assert chain == bits and len(bits) > 2000
+    # and the same through the library entry point on memory buffers, twice (context reuse)
+    for _ in range(2):
+        assert pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024") == bits
 
 
 def test_stress_10msps_block_and_window(pkg):
