@@ -93,7 +93,8 @@ def chain_workload(a, rank, world, local, dist, torch, pkg):
     dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, "cuda")
     got = np.frombuffer(out["bits"], np.uint8) - ord("0")
     s = "".join(map(str, sent))
-    ok = len(got) > 1500 and "".join(map(str, got[300:1300])) in s
+    # the tail: vdecode may need one 2048-symbol frame to settle its symbol-pair phase (vdecode.c:126-139)
+    ok = len(got) > 2500 and "".join(map(str, got[-1100:-100])) in s
     if rank == 0:
         nsamp = len(iq) // 2
         print(json.dumps({
