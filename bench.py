@@ -165,12 +165,19 @@ def main():
                          bits=bits, noise_mask=noise_mask))
     dec = segs[0]["dec"]
 
+    slab = 8 * chunk                                     # bits handed over per call and segment
+
     def step():
-        # every segment has its own decoder and HIP streams: the enqueues below return at once and
-        # the segments' kernels run concurrently on the device
+        # every segment has its own decoder and HIP streams.  With several segments per GPU the
+        # enqueues are interleaved slab by slab, so that launches of different segments sit next to
+        # each other in the device queues and overlap (one segment's loads/stores under another's
+        # arithmetic: 9.3 vs 15.4 us per launch with two, scratch/acs_bench.hip).
         for sg in segs:
             sg["dec"].init(0)
-            sg["dec"].stream_decode_dev(sg["d_syms"], nbits, a.delay, sg["d_out"])
+        for pos in range(0, nbits, slab):
+            n = min(slab, nbits - pos)
+            for sg in segs:
+                sg["dec"].stream_decode_dev(sg["d_syms"], n, a.delay, sg["d_out"], sym_offset=2 * pos, out_offset=pos)
 
     fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
     harness.timed_steps(step, 0, a.warmup, fence)

@@ -77,6 +77,27 @@ static double run_lds8_graph(int nlaunch, uint16_t *m0, uint16_t *m1, uint32_t *
   float ms = 0; hipEventElapsedTime(&ms, a, b);
   return ms * 1e3 / (reps * G);
 }
+// two independent decoders on two streams: do their launches overlap on the device?
+static double run_lds8_dual(int nlaunch, uint16_t *m0, uint16_t *m1, uint16_t *n0, uint16_t *n1, uint32_t *rows, uint32_t *rows2, int nrows,
+                            uint8_t *syms, V224Dev *ds, V224Dev *ds2, uint32_t *rowmeta, uint32_t *rowmeta2, hipStream_t st, hipStream_t st2) {
+  k_init<<<V224_NSTATES / 8 / 256, 256, 0, st>>>(m0, 0, ds, rowmeta, nrows);  k_init_start<<<1, 1, 0, st>>>(m0, 0);
+  k_init<<<V224_NSTATES / 8 / 256, 256, 0, st2>>>(n0, 0, ds2, rowmeta2, nrows); k_init_start<<<1, 1, 0, st2>>>(n0, 0);
+  uint16_t *m[2] = { m0, m1 }, *n[2] = { n0, n1 };
+  hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
+  auto go = [&](int cnt, unsigned pass0) {
+    for (int i = 0; i < cnt; i++) {
+      unsigned pass = pass0 + i; int row0 = (int)((pass * 8) % (unsigned)(nrows - 8));
+      k_acs_lds8<0><<<512, 512, 0, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, syms + 2 * ((pass * 8) % 4096), ds, pass, rowmeta);
+      k_acs_lds8<0><<<512, 512, 0, st2>>>(n[pass & 1], n[(pass & 1) ^ 1], rows2, row0, syms + 2 * ((pass * 8) % 4096), ds2, pass, rowmeta2);
+    }
+  };
+  go(100, 0); hipStreamSynchronize(st); hipStreamSynchronize(st2);
+  hipEventRecord(a, st); hipStreamWaitEvent(st2, a, 0);
+  go(nlaunch, 100);
+  hipEventRecord(c, st2); hipStreamWaitEvent(st, c, 0); hipEventRecord(b, st);
+  hipStreamSynchronize(st); hipStreamSynchronize(st2);
+  float ms = 0; hipEventElapsedTime(&ms, a, b); return ms * 1e3 / nlaunch;
+}
 template <int MODE>
 static double run_misc(int nlaunch, int nblk, V224Dev *ds, uint32_t *buf, uint32_t *buf2, hipStream_t st) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -137,6 +158,14 @@ int main(int argc, char **argv) {
   for (int rep = 0; rep < 2; rep++) {
 #define L(ABL, what) printf("LDS8 PK=%d ABL=%2d %-30s: %7.2f us/launch\n", LDS8_PK, ABL, what, run_lds8<ABL>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     L(0, "full") L(14, "arith + LDS only") L(30, "arith + LDS, no min")
+    {
+      uint16_t *n0, *n1; uint32_t *rows2, *rowmeta2; V224Dev *ds2; hipStream_t st2;
+      hipMalloc(&n0, V224_NSTATES * 2); hipMalloc(&n1, V224_NSTATES * 2); hipMalloc(&rows2, (size_t)nrows * V224_ROWWORDS * 4);
+      hipMalloc(&rowmeta2, nrows * 4); hipMalloc(&ds2, sizeof(V224Dev)); hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
+      double t = run_lds8_dual(nlaunch, m0, m1, n0, n1, rows, rows2, nrows, syms, ds, ds2, rowmeta, rowmeta2, st, st2);
+      printf("LDS8 ALIAS=%d two decoders on two streams: %7.2f us per launch PAIR (%.2f us per launch-equivalent)\n", LDS8_ALIAS, t, t / 2);
+      hipFree(n0); hipFree(n1); hipFree(rows2); hipFree(rowmeta2); hipFree(ds2);
+    }
     printf("LDS8 via hipGraph (128 launches per graph): %7.2f us/launch\n", run_lds8_graph(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     printf("LDS8 2 tiles per workgroup: %7.2f us/launch, alternating min: %7.2f\n", run_lds8<0, false, 2>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st), run_lds8<0, true, 2>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     printf("LDS8 alternating min tracking: %7.2f us/launch\n", run_lds8<0, true>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
