@@ -257,6 +257,40 @@ __global__ void k_chainback(const uint32_t *__restrict__ rows, const uint32_t *_
   }
 }
 
+// Same walk, six steps per memory round trip.  After j steps the state is
+// (c << (23-j)) | (s >> j) with c = the j decision bits read so far: only 2^j candidates, so one wave
+// fetches the decision of EVERY candidate of the next six steps at once (1+2+4+8+16+32 = 63 lanes,
+// one dependent-load latency), then resolves the six bits with readlane.  The bits leaving on the
+// right (what the port packs into data[]) are bits 0..5 of s: known before any load returns.
+__global__ __launch_bounds__(64) void k_chainback_spec(const uint32_t *__restrict__ rows,
+                                                       const uint32_t *__restrict__ rowmeta, int len,
+                                                       unsigned nbits, unsigned endstate,
+                                                       uint8_t *__restrict__ data) {
+  const unsigned lane = threadIdx.x;
+  const unsigned lvl = 31u - (unsigned)__clz((int)(lane + 1u));      // lane 0 -> 0, 1-2 -> 1, 3-6 -> 2, ...
+  const unsigned cand = lane + 1u - (1u << lvl);
+  unsigned st = endstate & V224_SMASK, acc = 0;
+  long long n = (long long)nbits - 1;                                // step index, as the port's nbits--
+  while (n >= 0) {
+    const int steps = n >= 5 ? 6 : (int)(n + 1);
+    unsigned d = 0;
+    if (lane < 63u && (int)lvl < steps) {
+      const unsigned cs = ((cand << (V224_SBITS - lvl)) | (st >> lvl)) & V224_SMASK;
+      d = get_decision(rows, rowmeta, (int)((unsigned long long)(n - lvl) % (unsigned)len), cs);
+    }
+    unsigned c = 0;
+    for (int j = 0; j < steps; j++) {
+      const unsigned nn = (unsigned)(n - j);
+      acc = (((st >> j) & 1u) << 7) | (acc >> 1);
+      if ((nn & 7u) == 0 && lane == 0) data[nn >> 3] = (uint8_t)acc;
+      const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)d, (int)((1u << j) - 1u + c));
+      c |= b << j;
+    }
+    st = ((c << (V224_SBITS - steps)) | (st >> steps)) & V224_SMASK;
+    n -= steps;
+  }
+}
+
 // decodeword, sse2.c:206-243: result = bit<<63 | result>>1 per step
 __global__ void k_decodeword(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta,
                              int len, int dp, int delay, unsigned endstate,
@@ -615,7 +649,8 @@ extern "C" int chainback_viterbi224(void *p, unsigned char *data, unsigned int n
     size_t nbytes = (nbits + 7) / 8;
     HIPCHK(hipSetDevice(v->dev));
     if (ensure_cap(&v->dout, &v->dout_cap, nbytes) != 0) return -1;
-    k_chainback<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, v->dout);
+    if (getenv("V224HIP_SERIAL_CHAINBACK")) k_chainback<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, v->dout);
+    else k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, v->dout);
     // the port writes data[n>>3] only where (n & 7) == 0, i.e. nbits/8 bytes (+1 if ragged)
     HIPCHK(hipMemcpyAsync(data, v->dout, nbytes, hipMemcpyDeviceToHost, v->st));
     HIPCHK(hipStreamSynchronize(v->st));

@@ -1,0 +1,24 @@
+import sys, time
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import numpy as np
+from conftest import load_pkg
+pkg = load_pkg()
+from importlib import import_module
+synth = import_module("isee3_decoder_amd.synth")
+nb = 1024
+syms, bits, _ = synth.coded_stream(1, nb, 4.0, 24.0, 0.0)
+d = pkg.Viterbi224(nb)
+for rep in range(3):
+    d.init(0); d.sync()
+    t0 = time.perf_counter(); d.update(syms, nb); d.sync(); t1 = time.perf_counter()
+    out = d.chainback(nb, 0); t2 = time.perf_counter()
+    print("update %.3f ms, chainback %.3f ms" % ((t1-t0)*1e3, (t2-t1)*1e3))
+# two decoders alternating frames
+d2 = pkg.Viterbi224(nb)
+t0 = time.perf_counter()
+for rep in range(4):
+    d.init(0); d2.init(0)
+    d.update(syms, nb); d2.update(syms, nb)
+    a = d.chainback(nb, 0); b = d2.chainback(nb, 0)
+t1 = time.perf_counter()
+print("2 decoders x 4 frames: %.3f ms per frame" % ((t1-t0)*1e3/8))

@@ -94,3 +94,22 @@ def test_pmdemod_oracle_recovers_carrier():
     for r in rep:
         assert abs(r["carrier_freq"] - 1000.25) < 0.5 and r["cn0"] > 40
     assert np.array_equal(out, pre.astype(np.int16))    # C cast = truncation toward zero
+
+
+def test_framer_byte_exact_vs_reference():
+    """bin/framer == the reference's framer.c on the same decoded bit stream."""
+    if not os.path.exists(os.path.join(orc.REF_DIR, "framer_ref")):
+        pytest.skip("oracle/_ref/framer_ref not prebuilt")
+    from conftest import load_pkg
+    pkg = load_pkg()
+    z = np.load(os.path.join(orc.GOLDEN, "vdecode_cli.npz"))
+    bits = z["flip/stdout"].tobytes() + z["forced_F/stdout"].tobytes()
+    # splice in two clean frames so that several sync words occur
+    sent = orc.gen_baseband(77, 2.0, 4200.0, 1.0, 1000.0, 0.0)[1]
+    bits += bytes(ord("0") + int(b) for b in sent)
+    env = dict(os.environ)
+    env.pop("LANG", None)
+    for args in ([], ["-r", "64"]):
+        want = subprocess.run([os.path.join(orc.REF_DIR, "framer_ref")] + args, input=bits, stdout=subprocess.PIPE, env=env, check=True).stdout
+        got = subprocess.run([pkg.cli_path("framer")] + args, input=bits, stdout=subprocess.PIPE, env=env, check=True).stdout
+        assert got == want and got.count(b"Frame ") >= 2
