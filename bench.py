@@ -69,7 +69,7 @@ def cpu_baseline(nbits_sample):
             "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nbits_sample, what, dt)}
 
 
-def chain_workload(a, rank, world, local, dist, torch, pkg):
+def chain_workload(a, rank, world, local, dist, torch, pkg, redev="cuda"):
     """BASELINE.json configs[2]/[3]: full pmdemod | symdemod | vdecode chain on synthetic int16 IQ,
     one independent capture per GPU (libisee3chain.so = the three C pipe stages as threads of the
     calling process; the capture is fed from host memory through a pipe, so PCIe and pipe copies are
@@ -90,7 +90,7 @@ def chain_workload(a, rank, world, local, dist, torch, pkg):
 
     fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
     dt = harness.timed_steps(step, a.steps, a.warmup, fence)
-    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, "cuda")
+    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, redev)
     got = np.frombuffer(out["bits"], np.uint8) - ord("0")
     s = "".join(map(str, sent))
     # the tail: vdecode may need one 2048-symbol frame to settle its symbol-pair phase (vdecode.c:126-139)
@@ -135,14 +135,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    # rehearsal mode for a one-GPU box: ISEE3_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+    # uses gloo for the barrier / MAX (RCCL refuses two ranks on one device)
+    one_dev = os.environ.get("ISEE3_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
+    redev = "cpu" if one_dev else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     pkg = load_pkg()
     if a.workload == "chain":
-        chain_workload(a, rank, world, local, dist, torch, pkg)
+        chain_workload(a, rank, world, local, dist, torch, pkg, redev)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -186,7 +195,7 @@ def main():
     dt = harness.timed_steps(step, a.steps, 0, fence)
     launches, ms, steps_timed = dec.acs_stats()
     dec.set_option("profile", 0)
-    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, "cuda")
+    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, redev)
     d_out, bits, noise_mask = segs[0]["d_out"], segs[0]["bits"], segs[0]["noise_mask"]
 
     # sanity: decoded bits equal sent bits away from the noise blocks (does not replace tests/)
