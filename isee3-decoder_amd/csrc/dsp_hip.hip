@@ -62,6 +62,8 @@ struct Symd {
   void *d_e; size_t e_cap;
   void *d_out; size_t out_cap;
   void *d_sym; size_t sym_cap;
+  void *d_part; size_t part_cap;
+  unsigned *d_flag;
 };
 
 __device__ __forceinline__ long long wave_incl_scan(long long v) {
@@ -144,6 +146,48 @@ __global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__
   energies[t] = energy;
 }
 
+// Parallel form of the same sum.  The reference adds (double)(sym*sym) symbol by symbol; as long as
+// every term and the running total stay below 2^53 each partial sum is an exactly representable integer
+// and the order of addition cannot matter, so the sum may be formed in u64 by many threads.  Thread =
+// offset (coalesced prefix reads), block = a slice of TS_SLICE symbols.  Any term or total >= 2^53 raises
+// `inexact`, and the host then runs the sequential kernel above for that window instead.
+#define TS_SLICE 16
+#define TS_LIMIT (1ull << 53)
+__global__ __launch_bounds__(256) void k_timesearch_part(const long long *__restrict__ P, int lo,
+                                                         const int *__restrict__ sw, int symbolclocks, int nsymbols,
+                                                         int noff, unsigned long long *__restrict__ part,
+                                                         unsigned *__restrict__ inexact) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= noff) return;
+  const long long *Pb = P + lo + t;
+  int i0 = blockIdx.y * TS_SLICE, i1 = i0 + TS_SLICE < nsymbols ? i0 + TS_SLICE : nsymbols;
+  unsigned long long acc = 0; unsigned bad = 0;
+  int k = 2 * i0 * symbolclocks;
+  for (int i = i0; i < i1; i++) {
+    long long sym = 0;
+    for (int j = 0; j < symbolclocks; j++, k += 2) {
+      long long a = Pb[sw[k]], b = Pb[sw[k + 1]], c = Pb[sw[k + 2]];
+      sym += -(b - a) + (c - b);
+    }
+    unsigned long long m = (unsigned long long)(sym < 0 ? -sym : sym);
+    if (m >= (1ull << 26)) bad = 1;               // sym^2 >= 2^52: be conservative
+    unsigned long long sq = m * m;
+    acc += sq;
+    if (acc >= TS_LIMIT) bad = 1;
+  }
+  part[(size_t)blockIdx.y * noff + t] = acc;
+  if (bad) atomicOr(inexact, 1u);
+}
+__global__ __launch_bounds__(256) void k_timesearch_fin(const unsigned long long *__restrict__ part, int nslices, int noff,
+                                                        double *__restrict__ energies, unsigned *__restrict__ inexact) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= noff) return;
+  unsigned long long acc = 0; unsigned bad = 0;
+  for (int s = 0; s < nslices; s++) { acc += part[(size_t)s * noff + t]; if (acc >= TS_LIMIT) bad = 1; }
+  energies[t] = (double)acc;
+  if (bad) atomicOr(inexact, 1u);
+}
+
 // symdemod.c:202-256: one thread per symbol; a single lane then sums sym^2 in order
 __global__ __launch_bounds__(256) void k_demod(const long long *__restrict__ P, const int *__restrict__ edges,
                                                int symbolclocks, int nsymbols, double gain,
@@ -169,6 +213,30 @@ __global__ void k_seq_energy(const long long *__restrict__ symv, int nsymbols, d
   for (int i = 0; i < nsymbols; i++) e += (double)(symv[i] * symv[i]);
   *energy = e;
 }
+// exact-integer form of the same sum by one block (see k_timesearch_part); *inexact != 0 => rerun k_seq_energy
+__global__ __launch_bounds__(256) void k_par_energy(const long long *__restrict__ symv, int nsymbols, double *energy,
+                                                    unsigned *__restrict__ inexact) {
+  __shared__ unsigned long long ws[256];
+  __shared__ unsigned wbad;
+  if (threadIdx.x == 0) wbad = 0;
+  __syncthreads();
+  unsigned long long acc = 0; unsigned bad = 0;
+  for (int i = threadIdx.x; i < nsymbols; i += 256) {
+    long long v = symv[i];
+    unsigned long long m = (unsigned long long)(v < 0 ? -v : v);
+    if (m >= (1ull << 26)) bad = 1;
+    acc += m * m;
+    if (acc >= TS_LIMIT) bad = 1;
+  }
+  ws[threadIdx.x] = acc;
+  if (bad) atomicOr(&wbad, 1u);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ws[threadIdx.x] += ws[threadIdx.x + o]; if (ws[threadIdx.x] >= TS_LIMIT) atomicOr(&wbad, 1u); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *energy = (double)ws[0]; *inexact = wbad; }
+}
 
 extern "C" void *symd_create(int max_samples) {
   Symd *h = (Symd *)calloc(1, sizeof(Symd));
@@ -181,6 +249,7 @@ extern "C" void *symd_create(int max_samples) {
   CHK(hipMalloc(&h->d_P, sizeof(long long) * ((size_t)h->cap + 1)));
   h->nblk_cap = (h->cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
   CHK(hipMalloc(&h->d_blk, sizeof(long long) * (size_t)h->nblk_cap));
+  CHK(hipMalloc(&h->d_flag, 2 * sizeof(unsigned)));
   return h;
 fail:
   symd_destroy(h);
@@ -192,7 +261,7 @@ extern "C" void symd_destroy(void *p) {
   (void)hipSetDevice(h->dev);
   if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
   (void)hipFree(h->d_s); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
-  (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym);
+  (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym); (void)hipFree(h->d_part); (void)hipFree(h->d_flag);
   free(h);
 }
 extern "C" int symd_load(void *p, const int16_t *samples, int n, int is_dev) {
@@ -230,10 +299,24 @@ extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks,
       return -1;
     }
     CHK(hipMemcpyAsync(h->d_idx, sw, sizeof(int) * (size_t)nsw, hipMemcpyHostToDevice, h->st));
-    k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks, nsymbols,
-                                                     noff, (double *)h->d_e);
-    CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
-    CHK(hipStreamSynchronize(h->st));
+    const int nslices = (nsymbols + TS_SLICE - 1) / TS_SLICE;
+    unsigned flag = 1;
+    if (!getenv("ISEE3DSP_SEQUENTIAL") && grow(&h->d_part, &h->part_cap, sizeof(unsigned long long) * (size_t)nslices * (size_t)noff) == 0) {
+      CHK(hipMemsetAsync(h->d_flag, 0, sizeof(unsigned), h->st));
+      k_timesearch_part<<<dim3((noff + 255) / 256, nslices), 256, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks,
+                                                                            nsymbols, noff, (unsigned long long *)h->d_part, h->d_flag);
+      k_timesearch_fin<<<(noff + 255) / 256, 256, 0, h->st>>>((const unsigned long long *)h->d_part, nslices, noff,
+                                                            (double *)h->d_e, h->d_flag);
+      CHK(hipMemcpyAsync(&flag, h->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, h->st));
+      CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
+      CHK(hipStreamSynchronize(h->st));
+    }
+    if (flag) {     // some sum left the exactly-representable range: redo in the reference's own order
+      k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks, nsymbols,
+                                                       noff, (double *)h->d_e);
+      CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
+      CHK(hipStreamSynchronize(h->st));
+    }
   }
   return 0;
 fail:
@@ -259,13 +342,20 @@ extern "C" int symd_demod(void *p, const int *edges, int symbolclocks, int nsymb
     uint8_t *dst = (out && out_is_dev) ? out : (uint8_t *)h->d_out;
     k_demod<<<(nsymbols + 255) / 256, 256, 0, h->st>>>(h->d_P, (const int *)h->d_idx, symbolclocks, nsymbols, gain,
                                                        (gain != 0 && out) ? dst : nullptr, (long long *)h->d_sym);
+    unsigned flag = 0;
     if (energy_sum) {
-      k_seq_energy<<<1, 64, 0, h->st>>>((const long long *)h->d_sym, nsymbols, (double *)h->d_e);
+      k_par_energy<<<1, 256, 0, h->st>>>((const long long *)h->d_sym, nsymbols, (double *)h->d_e, h->d_flag + 1);
       CHK(hipMemcpyAsync(energy_sum, h->d_e, sizeof(double), hipMemcpyDeviceToHost, h->st));
+      CHK(hipMemcpyAsync(&flag, h->d_flag + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->st));
     }
     if (gain != 0 && out && !out_is_dev)
       CHK(hipMemcpyAsync(out, h->d_out, (size_t)nsymbols, hipMemcpyDeviceToHost, h->st));
     CHK(hipStreamSynchronize(h->st));
+    if (energy_sum && (flag || getenv("ISEE3DSP_SEQUENTIAL"))) {
+      k_seq_energy<<<1, 64, 0, h->st>>>((const long long *)h->d_sym, nsymbols, (double *)h->d_e);
+      CHK(hipMemcpyAsync(energy_sum, h->d_e, sizeof(double), hipMemcpyDeviceToHost, h->st));
+      CHK(hipStreamSynchronize(h->st));
+    }
   }
   return 0;
 fail:
@@ -345,11 +435,20 @@ __global__ __launch_bounds__(256) void k_peak_partial(const double2 *__restrict_
     part[blockIdx.x].e = be; part[blockIdx.x].idx = bi;
   }
 }
-__global__ void k_peak_final(const PeakRec *__restrict__ part, int nparts, const double2 *__restrict__ spec, int N,
-                             pmd_peak *out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_peak_final(const PeakRec *__restrict__ part, int nparts,
+                                                    const double2 *__restrict__ spec, int N, pmd_peak *out) {
+  __shared__ PeakRec ws[256];
   double be = -1.0; int bi = -1;
-  for (int p = 0; p < nparts; p++) if (peak_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
+  for (int p = threadIdx.x; p < nparts; p += 256) if (peak_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
+  ws[threadIdx.x].e = be; ws[threadIdx.x].idx = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o && peak_better(ws[threadIdx.x + o].e, ws[threadIdx.x + o].idx, ws[threadIdx.x].e, ws[threadIdx.x].idx))
+      ws[threadIdx.x] = ws[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  be = ws[0].e; bi = ws[0].idx;
   out->peak = bi; out->maxenergy = be;
   if (bi >= 0) {
     int next = (bi + 1) % N, prev = (N + bi - 1) % N;
@@ -513,7 +612,7 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     if (nb < 1) nb = 1;
     k_peak_partial<<<nb, 256, 0, h->st>>>(h->spec, firstbin, lastbin, part);
-    k_peak_final<<<1, 64, 0, h->st>>>(part, nb, h->spec, h->N, dres);
+    k_peak_final<<<1, 256, 0, h->st>>>(part, nb, h->spec, h->N, dres);
     CHK(hipMemcpyAsync(out, dres, sizeof(pmd_peak), hipMemcpyDeviceToHost, h->st));
     CHK(hipStreamSynchronize(h->st));
   }
