@@ -223,3 +223,42 @@ def test_stress_10msps_block_and_window(pkg):
     sy_ref, ph_ref, en_ref = orc.symdemod(bb, samprate=int(fs), c_opt="1024", window=0.2)
     out = _run(pkg.cli_path("symdemod"), ["-q", "-r", str(int(fs)), "-c", "1024", "-w", "0.2"], bb.tobytes())
     assert out == sy_ref.tobytes() and len(out) >= 204
+
+
+# ---- edge cases the reference handles implicitly: empty / short / ragged inputs ---------------------
+def _ref(exe, args, data):
+    p = os.path.join(orc.REF_DIR, exe)
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/%s not prebuilt" % exe)
+    return subprocess.run([p] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True).stdout
+
+
+@pytest.mark.parametrize("nsym", [0, 1, 2, 399, 401, 403])
+def test_vdecode_cli_short_and_ragged_inputs(pkg, nsym):
+    """fewer symbols than the decode delay, an odd count, exactly one output bit: same stdout as vdecode.c"""
+    z = np.load(VG)
+    data = z["forced_F/syms"][:nsym].tobytes()
+    want = _ref("vdecode_port_ref", ["-q", "-F"], data)
+    assert _run(pkg.cli_path("vdecode"), ["-q", "-F"], data) == want
+    assert len(want) == max(0, nsym // 2 - 200)
+
+
+@pytest.mark.parametrize("seconds", [0.0, 0.3, 1.0, 1.01])
+def test_symdemod_cli_short_inputs(pkg, seconds):
+    """less than one window of samples => no output, like symdemod.c:124-125"""
+    bb, _ = orc.gen_baseband(55, 25000.0, seconds, amp=1500.0, noise_sigma=2000.0)
+    args = ["-q", "-r", "25000", "-c", "1024", "-w", "1.0"]
+    want = _ref("symdemod_ref", args, bb.tobytes())
+    assert _run(pkg.cli_path("symdemod"), args, bb.tobytes()) == want
+
+
+def test_pmdemod_cli_short_input_and_bad_option(pkg):
+    """a partial block is dropped (pmdemod.c:206-216); unknown option => exit 1 (:111-113);
+    carrier outside Nyquist => exit 1 (:116-121)"""
+    iq, _ = orc.gen_iq(56, 16384.0, 0.2, fc_hz=500.0)
+    assert _run(pkg.cli_path("pmdemod"), ["-q", "-r", "16384", "-b", "4"], iq.tobytes()) == b""
+    assert _run(pkg.cli_path("pmdemod"), ["-q", "-r", "16384", "-b", "4"], b"") == b""
+    p = subprocess.run([pkg.cli_path("pmdemod"), "-Z"], input=b"", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"unknown option" in p.stderr
+    p = subprocess.run([pkg.cli_path("pmdemod"), "-r", "1000", "-S", "900"], input=b"", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"outside Nyquist" in p.stderr
