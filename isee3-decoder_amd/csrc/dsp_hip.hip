@@ -410,6 +410,65 @@ __global__ __launch_bounds__(256) void k_fft_stage(const double2 *__restrict__ x
   y[q + 2 * ps + s] = make_double2(dr * w.x - di * w.y, dr * w.y + di * w.x);
 }
 
+// Radix-R Stockham stage, R = 4, 8, 16: thread t loads x[t + j*N/R] (unit stride across lanes), does the
+// R-point DFT in registers (radix-2 DIF network with constant twiddles, bit-reversed read-out), applies the
+// stage twiddle W_N^(p*s*k) from the half-circle table and stores y[q + R*p*s + k*s].  A 2^23-point
+// transform takes 6 launches instead of 23, a 2^18-point one 5 instead of 18.
+template <int R> struct FftConst;
+template <> struct FftConst<2>  { static constexpr int LG = 1; };
+template <> struct FftConst<4>  { static constexpr int LG = 2; };
+template <> struct FftConst<8>  { static constexpr int LG = 3; };
+template <> struct FftConst<16> { static constexpr int LG = 4; };
+// cos / sin of m*pi/8, m = 0..7 (omega_16^m = c - j s)
+__device__ __constant__ double k_c16[8] = { 1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+                                            0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613 };
+__device__ __constant__ double k_s16[8] = { 0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
+                                            1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173 };
+__host__ __device__ constexpr int brev(int v, int bits) { int r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i); return r; }
+
+template <int R>
+__global__ __launch_bounds__(256) void k_fft_radix(const double2 *__restrict__ x, double2 *__restrict__ y,
+                                                   const double2 *__restrict__ tw, int N, int s) {
+  constexpr int LG = FftConst<R>::LG;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N / R) return;
+  const int q = t & (s - 1), ps = t - q;
+  double2 a[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) a[j] = x[t + j * (N / R)];
+  // radix-2 DIF: span R/2, R/4, ... 1; twiddle omega_R^(m * R/(2*span)) for position m inside a span
+#pragma unroll
+  for (int span = R / 2; span >= 1; span >>= 1) {
+#pragma unroll
+    for (int base = 0; base < R; base += 2 * span) {
+#pragma unroll
+      for (int m = 0; m < span; m++) {
+        const double2 u = a[base + m], v = a[base + m + span];
+        a[base + m] = make_double2(u.x + v.x, u.y + v.y);
+        const double dr = u.x - v.x, di = u.y - v.y;
+        const int e = m * (8 / span);                    // exponent of omega_16 (multiples of 16/(2*span))
+        if (e == 0) a[base + m + span] = make_double2(dr, di);
+        else if (e == 4) a[base + m + span] = make_double2(di, -dr);          // * (-j)
+        else { const double c = k_c16[e], sn = k_s16[e];
+               a[base + m + span] = make_double2(dr * c + di * sn, di * c - dr * sn); }   // * (c - j sn)
+      }
+    }
+  }
+  // a[brev(k)] = b_k
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const double2 b = a[brev(k, LG)];
+    double2 w;
+    if (k == 0) w = make_double2(1.0, 0.0);
+    else {
+      const int idx = ps * k;                              // < N
+      if (idx < N / 2) w = tw[idx];
+      else { const double2 h = tw[idx - N / 2]; w = make_double2(-h.x, -h.y); }
+    }
+    y[q + R * ps + k * s] = make_double2(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+  }
+}
+
 struct PeakRec { double e; int idx; int pad; };
 __device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) {
   return e > be || (e == be && i > bi);     // ">=" while scanning upward == last maximum wins
@@ -597,14 +656,25 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
   if (firstbin < 0 || lastbin > h->N || firstbin > lastbin) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: bad bin range"); return -1; }
   CHK(hipSetDevice(h->dev));
   {
-    // logN stages ping-pong so that the last one lands in spec; buf is never written
+    // stages ping-pong so that the last one lands in spec; buf is never written.  Radix plan: the
+    // small remainder radix first (its short output runs matter least while s is tiny), then radix 16.
+    int radices[12], nst = 0, rem = h->logN;
+    if (getenv("ISEE3DSP_FFT_RADIX2")) { while (rem > 0) { radices[nst++] = 2; rem--; } }
+    else {
+      if (rem % 4) { radices[nst++] = 1 << (rem % 4); rem -= rem % 4; }
+      while (rem > 0) { radices[nst++] = 16; rem -= 4; }
+    }
     const double2 *src = h->buf;
     int s = 1;
-    for (int st = 0; st < h->logN; st++, s <<= 1) {
-      bool to_spec = ((h->logN - 1 - st) & 1) == 0;
+    for (int st = 0; st < nst; st++) {
+      bool to_spec = ((nst - 1 - st) & 1) == 0;
       double2 *dst = to_spec ? h->spec : h->tmp;
-      k_fft_stage<<<(h->N / 2 + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
-      src = dst;
+      const int R = radices[st], nthr = h->N / R;
+      if (R == 2) k_fft_stage<<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+      else if (R == 4) k_fft_radix<4><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+      else if (R == 8) k_fft_radix<8><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+      else k_fft_radix<16><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+      src = dst; s *= R;
     }
     PeakRec *part = (PeakRec *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak));
     pmd_peak *dres = (pmd_peak *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64));
