@@ -1,0 +1,91 @@
+"""Overlapped-segment decoding of one long capture (BASELINE.json configs[4]).
+
+The reference has no such notion: its stages are single sequential filters.  Cutting a capture is what
+lets one capture use several GPUs (or several concurrent chains on one GPU, whose kernels overlap).
+Each segment is a block-aligned slice of the IQ capture, extended to the left by `warm_blocks` FFT
+blocks so that symdemod's timing search, vdecode's symbol-pair phase (one 2048-symbol frame) and the
+Viterbi path history have settled before the segment's own samples begin.  Segments are decoded
+independently (no collective), then stitched on the host by matching decoded bits inside the overlap.
+
+This is NOT bit-exact by construction -- a decoder restarted inside the stream starts from different
+path metrics -- so the stitcher reports how many seams matched exactly; on a clean signal all do.
+"""
+import threading
+
+import numpy as np
+
+
+def plan_segments(nblocks, nseg, warm_blocks):
+    """[(first block incl. warm-up, first own block, end block)] for nseg near-equal block-aligned segments."""
+    edges = [round(i * nblocks / nseg) for i in range(nseg + 1)]
+    return [(max(0, edges[i] - warm_blocks), edges[i], edges[i + 1]) for i in range(nseg) if edges[i + 1] > edges[i]]
+
+
+def stitch(parts, probe_len=192):
+    """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments.
+    Returns (joined bits, seams matched, seams total)."""
+    out = parts[0]
+    ok = 0
+    for nxt in parts[1:]:
+        placed = False
+        # probe from the middle of the next segment's warm-up region onwards: settled, and still inside the overlap
+        for frac in (0.5, 0.65, 0.8, 0.35):
+            w = int(len(nxt) * 0 + frac * _overlap_bits(out, nxt))
+            probe = nxt[w:w + probe_len]
+            if len(probe) < probe_len:
+                continue
+            p = out.rfind(probe)
+            if p >= 0:
+                out = out[:p] + nxt[w:]
+                placed = True
+                break
+        if placed:
+            ok += 1
+        else:
+            out = out + nxt          # no exact match inside the overlap: keep everything, caller sees the count
+    return out, ok, len(parts) - 1
+
+
+def _overlap_bits(prev, nxt):
+    # the overlap cannot be longer than either part; use a generous bound, the search is by content
+    return min(len(prev), len(nxt), 4096)
+
+
+def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=3, concurrency=2, symrate="1024",
+                     decode_delay=200):
+    """Cut `iq` (int16 interleaved) into nseg overlapped segments, run the whole chain on each
+    (`concurrency` chains at a time in this process, so their kernels overlap on the device) and
+    stitch.  Returns (bits, seams_ok, seams, samples_processed_including_overlap)."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    N = 1 << int(np.rint(np.log2(samprate / binsize)))
+    nblocks = (len(iq) // 2) // N
+    plan = plan_segments(nblocks, nseg, warm_blocks)
+    parts = [None] * len(plan)
+    lock = threading.Lock()
+    todo = list(range(len(plan)))
+    errors = []
+
+    def worker():
+        while True:
+            with lock:
+                if not todo:
+                    return
+                i = todo.pop(0)
+            b0, _, b1 = plan[i]
+            try:
+                parts[i] = run_chain(iq[2 * b0 * N:2 * b1 * N], samprate=samprate, binsize=binsize, symrate=symrate,
+                                     decode_delay=decode_delay)
+            except Exception as e:                      # noqa: BLE001
+                errors.append(e)
+                return
+
+    threads = [threading.Thread(target=worker) for _ in range(max(1, concurrency))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    bits, ok, seams = stitch(parts)
+    processed = sum((b1 - b0) * N for b0, _, b1 in plan)
+    return bits, ok, seams, processed
