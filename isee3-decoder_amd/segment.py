@@ -21,16 +21,18 @@ def plan_segments(nblocks, nseg, warm_blocks):
     return [(max(0, edges[i] - warm_blocks), edges[i], edges[i + 1]) for i in range(nseg) if edges[i + 1] > edges[i]]
 
 
-def stitch(parts, probe_len=192):
-    """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments.
+def stitch(parts, overlap_bits, probe_len=160):
+    """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments;
+    overlap_bits[i]: roughly how many decoded bits part i+1 shares with part i (its warm-up region).
+    A probe is taken from the settled end of that region and located in the previous part.
     Returns (joined bits, seams matched, seams total)."""
     out = parts[0]
     ok = 0
-    for nxt in parts[1:]:
+    for nxt, ovl in zip(parts[1:], overlap_bits):
         placed = False
-        # probe from the middle of the next segment's warm-up region onwards: settled, and still inside the overlap
-        for frac in (0.5, 0.65, 0.8, 0.35):
-            w = int(len(nxt) * 0 + frac * _overlap_bits(out, nxt))
+        # the first ~1100 bits of a restarted decode are unreliable (start-up delay + one frame for the
+        # symbol-pair phase decision, vdecode.c:126-139): probe between there and the end of the overlap
+        for w in range(max(1100, ovl - 300), 1000, -150):
             probe = nxt[w:w + probe_len]
             if len(probe) < probe_len:
                 continue
@@ -44,11 +46,6 @@ def stitch(parts, probe_len=192):
         else:
             out = out + nxt          # no exact match inside the overlap: keep everything, caller sees the count
     return out, ok, len(parts) - 1
-
-
-def _overlap_bits(prev, nxt):
-    # the overlap cannot be longer than either part; use a generous bound, the search is by content
-    return min(len(prev), len(nxt), 4096)
 
 
 def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=3, concurrency=2, symrate="1024",
@@ -86,6 +83,8 @@ def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=3, conc
         t.join()
     if errors:
         raise errors[0]
-    bits, ok, seams = stitch(parts)
+    bps = (1024.545058 / 2 if symrate in (None, "1024") else float(symrate) / 2)
+    overlaps = [int((plan[i + 1][1] - plan[i + 1][0]) * N / samprate * bps) for i in range(len(plan) - 1)]
+    bits, ok, seams = stitch(parts, overlaps)
     processed = sum((b1 - b0) * N for b0, _, b1 in plan)
     return bits, ok, seams, processed
