@@ -3,8 +3,9 @@
 The reference has no such notion: its stages are single sequential filters.  Cutting a capture is what
 lets one capture use several GPUs (or several concurrent chains on one GPU, whose kernels overlap).
 Each segment is a block-aligned slice of the IQ capture, extended to the left by `warm_blocks` FFT
-blocks so that symdemod's timing search, vdecode's symbol-pair phase (one 2048-symbol frame) and the
-Viterbi path history have settled before the segment's own samples begin.  Segments are decoded
+blocks so that symdemod's timing search, vdecode's symbol-pair phase (decided once per 4096 symbols) and
+the Viterbi path history have settled before the segment's own samples begin: the warm-up must span
+more than ~2600 decoded bits (5.2 s at 512 bit/s).  Segments are decoded
 independently (no collective), then stitched on the host by matching decoded bits inside the overlap.
 
 This is NOT bit-exact by construction -- a decoder restarted inside the stream starts from different
@@ -30,9 +31,10 @@ def stitch(parts, overlap_bits, probe_len=160):
     ok = 0
     for nxt, ovl in zip(parts[1:], overlap_bits):
         placed = False
-        # the first ~1100 bits of a restarted decode are unreliable (start-up delay + one frame for the
-        # symbol-pair phase decision, vdecode.c:126-139): probe between there and the end of the overlap
-        for w in range(max(1100, ovl - 300), 1000, -150):
+        # the first ~2300 bits of a restarted decode are unreliable: start-up delay, and vdecode decides its
+        # symbol-pair phase only once per 2048 ODD symbols = two frames (vdecode.c:122-139).  Probe between
+        # there and the end of the overlap.
+        for w in range(max(2300, ovl - 300), 2200, -100):
             probe = nxt[w:w + probe_len]
             if len(probe) < probe_len:
                 continue
@@ -48,7 +50,7 @@ def stitch(parts, overlap_bits, probe_len=160):
     return out, ok, len(parts) - 1
 
 
-def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=3, concurrency=2, symrate="1024",
+def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=7, concurrency=2, symrate="1024",
                      decode_delay=200):
     """Cut `iq` (int16 interleaved) into nseg overlapped segments, run the whole chain on each
     (`concurrency` chains at a time in this process, so their kernels overlap on the device) and
