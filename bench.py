@@ -65,8 +65,19 @@ def cpu_baseline(nbits_sample):
         done += n
     dt = time.perf_counter() - t0
     d.close()
-    return {"value": round(2 * nbits_sample / dt / 1e6, 6), "unit": "Msymbols/s", "cores": 1, "kind": kind,
-            "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nbits_sample, what, dt)}
+    res = {"value": round(2 * nbits_sample / dt / 1e6, 6), "unit": "Msymbols/s", "cores": 1, "kind": kind,
+           "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nbits_sample, what, dt)}
+    if orc.have_ref():          # the parity target itself, for the record (not the x100 denominator)
+        p = orc.RefV224(64, "port")
+        p.init(0)
+        n = 320
+        t0 = time.perf_counter()
+        for i in range(0, n, 64):
+            p.update(syms[2 * i:2 * (i + 64)], 64)
+        res["port_value"] = round(2 * n / (time.perf_counter() - t0) / 1e6, 6)
+        res["port_sample"] = "%d trellis steps, viterbi224_port.c (oracle/_ref), 1 core" % n
+        p.close()
+    return res
 
 
 def chain_workload(a, rank, world, local, dist, torch, pkg, redev="cuda"):

@@ -197,3 +197,23 @@ def test_stream_fixture_full_lds_engine(pkg):
 
 def test_seeded_stream_vs_oracle_lds_engine(pkg):
     test_seeded_stream_vs_oracle(pkg, 2, 0)
+
+
+def test_long_stream_vs_oracle_100k_bits(pkg):
+    """BASELINE configs[0]/[1] at a larger size: 2*10^5 symbols (coded, 3 dB, 5 % pure-noise blocks) through
+    the default engine and through the CPU oracle (port semantics) -- every decoded bit equal."""
+    nbits, delay = 100_000, 200
+    syms, _ = orc.gen_coded_stream(9100, nbits, 3.0, 24.0, 5)
+    o = orc.OracleV224(delay + 1, orc.FAST)
+    o.init(0)
+    want = np.empty(nbits, np.uint8)
+    for u in range(nbits):
+        o.update(syms[2 * u:2 * u + 2], 1)
+        want[u] = o.decodebit(delay, 0) if u + 1 >= delay else 0xff
+    d = pkg.Viterbi224(delay + 2 * 1024)
+    d.init(0)
+    got = d.stream_decode(syms, delay)
+    assert np.array_equal(got, want)
+    assert d.min_metric() >= 0 and 0 < d.max_metric() - d.min_metric() < 1000 + 23 * 510
+    o.close()
+    d.close()
