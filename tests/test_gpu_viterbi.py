@@ -217,3 +217,23 @@ def test_long_stream_vs_oracle_100k_bits(pkg):
     assert d.min_metric() >= 0 and 0 < d.max_metric() - d.min_metric() < 1000 + 23 * 510
     o.close()
     d.close()
+
+
+@pytest.mark.parametrize("dist", ["uniform", "coded3dB"])
+def test_config1_framed_frames_vs_oracle(pkg, dist):
+    """BASELINE configs[0] shape (vtest224: init / update(1000) / chainback per frame),
+    12 frames per distribution through ONE decoder object, every frame's bytes equal to the oracle's."""
+    framebits, nframes = 1000, 12
+    d = pkg.Viterbi224(framebits)
+    o = orc.OracleV224(framebits, orc.FAST)
+    for f in range(nframes):
+        if dist == "uniform":
+            syms = orc.gen_uniform(7000 + f, 2 * framebits)
+        else:
+            syms, _ = orc.gen_coded_frame(7100 + f, framebits, 3.0, 24.0)
+        for dec in (d, o):
+            dec.init(0)
+            dec.update(syms, framebits)
+        assert np.array_equal(d.chainback(framebits, 0), o.chainback(framebits, 0)), "frame %d" % f
+    d.close()
+    o.close()
