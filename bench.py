@@ -224,7 +224,7 @@ def main():
     nseg = world * a.segments_per_gpu
     mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
     eng = a.engine if a.engine >= 0 else int(os.environ.get("V224HIP_ENGINE", "2"))
-    chunk = a.chunk or (1024 if eng == 2 else 1020)
+    chunk = a.chunk or (1024 if eng == 2 else 1020)           # 1020 = 68 x 15 = 204 x 5
     segs = []
     for g in mine:
         syms, bits, noise_mask = synth.coded_stream(1000 + g, nbits, 3.0, 24.0, 1.0)
@@ -275,7 +275,7 @@ def main():
         ach = ALG_BYTES_PER_STEP * steps_per_launch / (avg_ms * 1e-3) / 1e9 if launches else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        kern = {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8"}[eng]
+        kern = {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8", 3: "k_acs_lds15"}[eng]
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel") == kern:       # PMC passes cannot share a run with the timing: committed constant
@@ -289,8 +289,8 @@ def main():
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "viterbi224 ACS+chainback streaming, 2^23 states, 8-bit soft syms, "
                                    "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
-                       "engine": {0: "simple", 1: "fused", 2: "lds8"}[eng],
-                       "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8}[eng],
+                       "engine": {0: "simple", 1: "fused", 2: "lds8", 3: "lds15"}[eng],
+                       "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8, 3: 15}[eng],
                        "chunk_bits": chunk,
                        "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,

@@ -21,6 +21,8 @@ extern "C" {
 #define V224HIP_ENGINE_SIMPLE 0  /* one trellis step per launch, decisions in the port's bit order */
 #define V224HIP_ENGINE_FUSED  1  /* register-resident radix-2^k passes, permuted decision layout  */
 #define V224HIP_ENGINE_LDS    2  /* LDS-staged two-level passes, 8 trellis steps per launch        */
+#define V224HIP_ENGINE_LDS15  3  /* LDS-staged four-level passes, 15 steps per launch, metrics kept
+                                    in a tile-major order between launches                        */
 
 /* Number of HIP devices visible / select the device used by subsequent create calls of this
  * thread (default: device 0, or $V224HIP_DEVICE).  -1 on error. */

@@ -65,6 +65,9 @@ struct V224 {
   unsigned long long nsteps;// trellis steps since init
   unsigned pass;            // ACS launches since init (minima ping-pong index)
   bool min_valid;           // blkmin[pass & 1] describes the current metric buffer
+  int layout;               // 0: m[cur] is in natural state order; 1: in the L15 tile order (v224_lds15.hip.inc)
+  bool fresh;               // nothing has run since init: m[cur] is uniform except at `start`
+  unsigned start;
   int chunk;                // stream chunk (bits)
   int profile;              // time every profile-th run of ACS launches (0 = off)
   unsigned long long launches_seen;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(256) void k_acs_simple(const uint16_t *__restrict__
 // ------------------------------------------------------------------------------------------
 #include "v224_fused.hip.inc"
 #include "v224_lds.hip.inc"
+#include "v224_lds15.hip.inc"
 
 __device__ __forceinline__ unsigned get_decision(const uint32_t *__restrict__ rows,
                                                  const uint32_t *__restrict__ rowmeta,
@@ -221,6 +225,7 @@ __device__ __forceinline__ unsigned get_decision(const uint32_t *__restrict__ ro
   unsigned meta = rowmeta[row];
   if (meta == V224_META_PORT) return (r[state >> 5] >> (state & 31)) & 1u;
   if (meta & (1u << 16)) return lds8_get_decision(r, meta & 0xffu, state);
+  if (meta & (1u << 17)) return lds15_get_decision(r, meta & 0xffu, state);
   return fused_get_decision(r, meta, state);
 }
 
@@ -407,8 +412,13 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   if (v->K < 1) v->K = 1;
   if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;
   v->dev = g_device >= 0 ? g_device : env_int("V224HIP_DEVICE", 0);
-  v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : 1020);   // whole passes per chunk
+  v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : 1020);   // whole passes per chunk (1020 = 68 x 15)
   HIPCHK(hipSetDevice(v->dev));
+  if (v->engine == V224HIP_ENGINE_LDS15) {       // 133 KiB of dynamic LDS per workgroup: above the default cap
+    HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
+  }
   HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&v->m[0], sizeof(uint16_t) * V224_NSTATES));
@@ -457,6 +467,7 @@ extern "C" int init_viterbi224(void *p, int starting_state) {
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
   v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0; v->min_valid = true;
+  v->layout = 0; v->fresh = true; v->start = (unsigned)starting_state & V224_SMASK;
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
   k_init_start<<<1, 1, 0, v->st>>>(v->m[0], (unsigned)starting_state & V224_SMASK);
   HIPCHK(hipGetLastError());
@@ -511,6 +522,25 @@ static void ensure_min_valid(V224 *v) {
   v->min_valid = true;
 }
 
+// Bring m[cur] into the wanted order (0 natural, 1 L15).  Right after init only the start state differs
+// from the fill, so the switch is a two-element patch; otherwise one transposing copy into the other buffer
+// (the per-workgroup minima describe the same values before and after).
+__global__ void k_move_start(uint16_t *m, unsigned from, unsigned to) {
+  m[from] = (uint16_t)(V224_BASE + 1000u); m[to] = (uint16_t)V224_BASE;
+}
+static void ensure_layout(V224 *v, int want) {
+  if (v->layout == want) return;
+  if (v->fresh) {
+    const unsigned nat = v->start, l15 = l15_phys(v->start);
+    k_move_start<<<1, 1, 0, v->st>>>(v->m[v->cur], want ? nat : l15, want ? l15 : nat);
+  } else {
+    if (want) k_l15_from_nat<<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1]);
+    else      k_l15_to_nat<<<512, 512, 0, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1]);
+    v->cur ^= 1;
+  }
+  v->layout = want;
+}
+
 static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
   int done = 0;
   unsigned nlaunch = 0;
@@ -519,12 +549,34 @@ static int enqueue_acs(V224 *v, const uint8_t *d_syms, int nbits) {
   EvPair ev; const bool timed = prof_begin(v, &ev);
   while (done < nbits) {
     int k = 1;
+    if (v->engine == V224HIP_ENGINE_LDS15 && nbits - done >= 15 && v->len >= 15) {
+      // 15 steps per launch on the L15 tile order; the pass may wrap the ring.  Minimum tracking alternates
+      // (adjust, no publish) / (no adjust, publish) as below; the last full pass of a run publishes.
+      ensure_layout(v, 1);
+      const bool last = (nbits - done - 15) < 15;
+      const bool tin = v->min_valid, tout = !tin || last;
+#define LDS15_GO(TIN, TOUT) k_acs_lds15<0, TIN, TOUT><<<256, 1024, L15_LDS_BYTES, v->st>>>(v->m[v->cur], v->m[v->cur ^ 1], \
+                               v->rows, v->dp, v->len, d_syms + 2 * done, v->ds, v->pass, v->rowmeta)
+      if (tin && tout) LDS15_GO(true, true); else if (tin) LDS15_GO(true, false); else LDS15_GO(false, true);
+#undef LDS15_GO
+      v->min_valid = tout;
+      v->fresh = false;
+      nlaunch++;
+      v->cur ^= 1; v->pass++;
+      v->dp = (v->dp + 15) % v->len;
+      v->nsteps += 15u;
+      done += 15;
+      continue;
+    }
+    ensure_layout(v, 0);
+    v->fresh = false;
+    const bool lds8 = v->engine == V224HIP_ENGINE_LDS || v->engine == V224HIP_ENGINE_LDS15;
     if (v->engine != V224HIP_ENGINE_SIMPLE) {
-      k = v->engine == V224HIP_ENGINE_LDS ? 8 : v->K;
+      k = lds8 ? 8 : v->K;
       if (k > nbits - done) k = nbits - done;
       if (k > v->len - v->dp) k = v->len - v->dp;      // a pass never wraps the ring
     }
-    if (v->engine == V224HIP_ENGINE_LDS && k == 8) {
+    if (lds8 && k == 8) {
       // minimum tracking is split over two launches where possible: (adjust, no publish) then
       // (no adjust, publish).  The last launch of a run always publishes, so every other kernel
       // (remainder passes, traceback helpers, the next call) finds valid minima.
@@ -597,6 +649,7 @@ extern "C" int v224hip_update_dev(void *p, const uint8_t *d_syms, int nbits) {
 
 static int best_state(V224 *v, unsigned *state) {
   unsigned *d = (unsigned *)v->dmisc;
+  ensure_layout(v, 0);
   ensure_min_valid(v);
   HIPCHK(hipMemsetAsync(d, 0xff, sizeof(unsigned), v->st));
   k_argmin<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, d);
@@ -798,6 +851,7 @@ extern "C" int v224hip_export_metrics(void *p, uint32_t *out) {
   if (!v) return -1;
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipMalloc(&d, (size_t)V224_NSTATES * sizeof(uint32_t)));
+  ensure_layout(v, 0);
   ensure_min_valid(v);
   k_export_metrics<<<V224_NSTATES / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, d);
   HIPCHK(hipMemcpyAsync(out, d, (size_t)V224_NSTATES * sizeof(uint32_t), hipMemcpyDeviceToHost, v->st));

@@ -11,7 +11,7 @@
       asm volatile(INSN("%0") INSN("%1") INSN("%2") INSN("%3") INSN("%4") INSN("%5") INSN("%6") INSN("%7") \
                    INSN("%0") INSN("%1") INSN("%2") INSN("%3") INSN("%4") INSN("%5") INSN("%6") INSN("%7") \
                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
-                   : "v"(b), "v"(c));                                                            \
+                   : "v"(b), "v"(c));   /* %9 is clobbered by the mixed kernels: harmless, it is only an input value */                                                            \
     }                                                                                            \
     out[blockIdx.x * 256 + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7]; \
   }
@@ -35,6 +35,44 @@
 #define I_OR3(r) "v_or3_b32 " r ", " r ", %8, %9\n"
 #define I_CNDM(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n"
 #define I_MINU16(r) "v_min_u16 " r ", " r ", %8\n"
+#define I_MIX_PKADD_AND(r) "v_pk_add_u16 " r ", " r ", %8\n" "v_and_b32 %9, %9, %8\n"
+#define I_MIX_PKADD_ADD(r) "v_pk_add_u16 " r ", " r ", %8\n" "v_add_u32 %9, %9, %8\n"
+#define I_MIX_PKMIN_SHR(r) "v_pk_min_u16 " r ", " r ", %8\n" "v_lshrrev_b32 %9, 1, %9\n"
+#define I_MIX_BFI_AND(r) "v_bfi_b32 " r ", %8, %8, " r "\n" "v_and_b32 %9, %9, %8\n"
+#define I_MIX_PKADD_PKMIN(r) "v_pk_add_u16 " r ", " r ", %8\n" "v_pk_min_u16 %9, %9, %8\n"
+#define I_MIX_ADD_AND(r) "v_add_u32 " r ", " r ", %8\n" "v_and_b32 %9, %9, %8\n"
+// grouped: 8 packed ops then 8 VOP2 ops per iteration (same totals as k_mix_pkadd_and)
+__global__ __launch_bounds__(256) void k_grp_pkadd_and(unsigned *out, unsigned seed) {
+  unsigned a[8], c[8], b = seed | 3;
+  for (int k = 0; k < 8; k++) { a[k] = threadIdx.x * (k + 3) + seed; c[k] = a[k] ^ 0x55; }
+  for (int i = 0; i < ITER; i++) {
+    asm volatile("v_pk_add_u16 %0, %0, %16\n v_pk_add_u16 %1, %1, %16\n v_pk_add_u16 %2, %2, %16\n v_pk_add_u16 %3, %3, %16\n"
+                 "v_pk_add_u16 %4, %4, %16\n v_pk_add_u16 %5, %5, %16\n v_pk_add_u16 %6, %6, %16\n v_pk_add_u16 %7, %7, %16\n"
+                 "v_and_b32 %8, %8, %16\n v_and_b32 %9, %9, %16\n v_and_b32 %10, %10, %16\n v_and_b32 %11, %11, %16\n"
+                 "v_and_b32 %12, %12, %16\n v_and_b32 %13, %13, %16\n v_and_b32 %14, %14, %16\n v_and_b32 %15, %15, %16\n"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : "v"(b));
+  }
+  unsigned r = 0; for (int k = 0; k < 8; k++) r ^= a[k] ^ c[k];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+// alternating with the same 16 registers
+__global__ __launch_bounds__(256) void k_alt_pkadd_and(unsigned *out, unsigned seed) {
+  unsigned a[8], c[8], b = seed | 3;
+  for (int k = 0; k < 8; k++) { a[k] = threadIdx.x * (k + 3) + seed; c[k] = a[k] ^ 0x55; }
+  for (int i = 0; i < ITER; i++) {
+    asm volatile("v_pk_add_u16 %0, %0, %16\n v_and_b32 %8, %8, %16\n v_pk_add_u16 %1, %1, %16\n v_and_b32 %9, %9, %16\n"
+                 "v_pk_add_u16 %2, %2, %16\n v_and_b32 %10, %10, %16\n v_pk_add_u16 %3, %3, %16\n v_and_b32 %11, %11, %16\n"
+                 "v_pk_add_u16 %4, %4, %16\n v_and_b32 %12, %12, %16\n v_pk_add_u16 %5, %5, %16\n v_and_b32 %13, %13, %16\n"
+                 "v_pk_add_u16 %6, %6, %16\n v_and_b32 %14, %14, %16\n v_pk_add_u16 %7, %7, %16\n v_and_b32 %15, %15, %16\n"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : "v"(b));
+  }
+  unsigned r = 0; for (int k = 0; k < 8; k++) r ^= a[k] ^ c[k];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+KERN(k_mix_pkadd_and, I_MIX_PKADD_AND) KERN(k_mix_pkadd_add, I_MIX_PKADD_ADD) KERN(k_mix_pkmin_shr, I_MIX_PKMIN_SHR)
+KERN(k_mix_bfi_and, I_MIX_BFI_AND) KERN(k_mix_pkadd_pkmin, I_MIX_PKADD_PKMIN) KERN(k_mix_add_and, I_MIX_ADD_AND)
 KERN(k_add, I_ADD) KERN(k_sub, I_SUB) KERN(k_pkadd, I_PKADD) KERN(k_pksub, I_PKSUB) KERN(k_pkmin, I_PKMIN)
 KERN(k_pkshr, I_PKSHR) KERN(k_pkmad, I_PKMAD) KERN(k_shr, I_SHR) KERN(k_and, I_AND) KERN(k_bfi, I_BFI)
 KERN(k_andor, I_ANDOR) KERN(k_lshlor, I_LSHLOR) KERN(k_perm, I_PERM) KERN(k_align, I_ALIGN) KERN(k_min, I_MIN)
@@ -50,11 +88,13 @@ template <typename F> static void run(const char *name, F kern, unsigned *out) {
     double n = (double)waves * ITER * 16;
     printf("  w%d: %5.2f cyc", waves, ms * 1e6 / n * 2.4);
   }
-  printf("   (cycles per wave-instruction per SIMD at 2.4 GHz)\n");
+  printf("   (cycles per asm slot; mixed kernels have 2 instructions per slot)\n");
 }
 int main() {
   unsigned *out; hipMalloc(&out, 256 * 8 * 256 * 4 * 4);
 #define R(n) run(#n, n, out);
+  R(k_grp_pkadd_and) R(k_alt_pkadd_and)
+  R(k_mix_pkadd_and) R(k_mix_pkadd_add) R(k_mix_pkmin_shr) R(k_mix_bfi_and) R(k_mix_pkadd_pkmin) R(k_mix_add_and)
   R(k_add) R(k_sub) R(k_pkadd) R(k_pksub) R(k_pkmin) R(k_pkshr) R(k_pkmad) R(k_shr) R(k_and) R(k_bfi) R(k_andor)
   R(k_lshlor) R(k_perm) R(k_align) R(k_min) R(k_add3) R(k_fma) R(k_or3) R(k_minu16)
   return 0;

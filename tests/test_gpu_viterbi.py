@@ -199,6 +199,38 @@ def test_seeded_stream_vs_oracle_lds_engine(pkg):
     test_seeded_stream_vs_oracle(pkg, 2, 0)
 
 
+# ---- engine LDS15 (15 steps per launch, tile-major metric order between launches) --------------
+@pytest.mark.parametrize("name", _names())
+def test_framed_fixture_lds15_engine(pkg, name):
+    """1024-bit frames = 68 full passes + a 4-step remainder through the natural-order kernels: both
+    order conversions, every decision row and the final metrics are checked."""
+    test_framed_fixture(pkg, name, 3, 0)
+
+
+def test_stream_fixture_full_lds15_engine(pkg):
+    """chunk 510 = 34 passes; ring of 200 + 1020 rows is not a multiple of 15, so passes wrap it."""
+    test_stream_fixture_full(pkg, 3, 0)
+
+
+def test_seeded_stream_vs_oracle_lds15_engine(pkg):
+    """ragged pieces and chunk 256 = 17 passes + 1: switches between the two metric orders all the time"""
+    test_seeded_stream_vs_oracle(pkg, 3, 0)
+
+
+def test_lds15_equals_lds8_on_a_long_stream(pkg):
+    nbits, delay = 60_000, 200
+    syms, _ = orc.gen_coded_stream(9200, nbits, 2.5, 24.0, 5)
+    outs = []
+    for engine in (2, 3):
+        d = pkg.Viterbi224(delay + 2 * 1024, engine, 0)
+        d.init(0)
+        outs.append(d.stream_decode(syms, delay))
+        m = d.export_metrics()
+        outs.append(m - m.min())
+        d.close()
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])
+
+
 def test_long_stream_vs_oracle_100k_bits(pkg):
     """BASELINE configs[0]/[1] at a larger size: 2*10^5 symbols (coded, 3 dB, 5 % pure-noise blocks) through
     the default engine and through the CPU oracle (port semantics) -- every decoded bit equal."""
