@@ -223,7 +223,7 @@ def main():
     nbits = a.symbols // 2
     nseg = world * a.segments_per_gpu
     mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
-    eng = a.engine if a.engine >= 0 else int(os.environ.get("V224HIP_ENGINE", "2"))
+    eng = a.engine if a.engine >= 0 else int(os.environ.get("V224HIP_ENGINE", "3"))
     chunk = a.chunk or (1024 if eng == 2 else 1020)           # 1020 = 68 x 15 = 204 x 5
     segs = []
     for g in mine:

@@ -47,7 +47,7 @@ static int sy_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, doubl
 static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o, double *es) { return symd_demod(h, e, sc, ns, g, o, 0, es); }
 static void sy_destroy(void *h) { symd_destroy(h); }
 
-static int g_chunk = 1024;
+static int g_chunk = 1020;
 static void *vd_create(int len) { void *h = create_viterbi224(len); if (h) v224hip_set_option(h, "chunk", g_chunk); return h; }
 static int vd_init(void *h, int s) { return init_viterbi224(h, s); }
 static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) { return v224hip_stream_decode(h, s, n, d, o); }
@@ -108,7 +108,7 @@ static int chain_run(const isee3_chain_opts *co, FILE *in, FILE *out) {
   va.o.decode_delay = co->decode_delay;
   pa.o.quiet = sa.o.quiet = va.o.quiet = !co->verbose;
   if (getenv("V224HIP_CHUNK")) g_chunk = atoi(getenv("V224HIP_CHUNK"));
-  if (g_chunk < 8) g_chunk = 1024;
+  if (g_chunk < 8) g_chunk = 1020;
   if (pipe(p1) || pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() failed"); return 2; }
 #ifdef F_SETPIPE_SZ
   fcntl(p1[1], F_SETPIPE_SZ, 1 << 20); fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);

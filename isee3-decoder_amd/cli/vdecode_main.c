@@ -8,7 +8,7 @@
 #include "vdecode_core.h"
 #include "../../include/viterbi224_hip.h"
 
-static int g_chunk = 1024;
+static int g_chunk = 1020;      /* 68 passes of 15 steps (engine LDS15); any value works */
 static void *eng_create(int len) {
   void *h = create_viterbi224(len);
   if (h) v224hip_set_option(h, "chunk", g_chunk);
@@ -26,8 +26,8 @@ int main(int argc, char **argv) {
   const char *lang = getenv("LANG");
   setlocale(LC_ALL, lang ? lang : "en_US.utf8");        /* vdecode.c:60-63 */
   vdecode_parse_args(&o, argc, argv);
-  int chunk = getenv("V224HIP_CHUNK") ? atoi(getenv("V224HIP_CHUNK")) : 1024;
-  if (chunk < 1) chunk = 1024;
+  int chunk = getenv("V224HIP_CHUNK") ? atoi(getenv("V224HIP_CHUNK")) : 1020;
+  if (chunk < 1) chunk = 1020;
   g_chunk = chunk;
   vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 2 * chunk };
   if (vdecode_run(&o, &e, 0, stdout, stderr, &r) != 0) {

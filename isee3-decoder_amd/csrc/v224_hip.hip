@@ -407,7 +407,7 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   }
   v = new V224();
   v->len = len;
-  v->engine = engine >= 0 ? engine : env_int("V224HIP_ENGINE", V224HIP_ENGINE_LDS);
+  v->engine = engine >= 0 ? engine : env_int("V224HIP_ENGINE", V224HIP_ENGINE_LDS15);
   v->K = k > 0 ? k : env_int("V224HIP_K", FUSED_DEFAULT_K);
   if (v->K < 1) v->K = 1;
   if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;

@@ -1,0 +1,65 @@
+// does the speed of the LDS15 pass depend on where the two metric buffers sit?  One arena, every (a, b) offset
+// pair in 2 MiB steps mod 16 MiB; prints the memory-only (ABL=1) and the full launch time per pair.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DL15_DSTORE=1 -o scratch/l15_place scratch/l15_place.hip
+#include "../isee3-decoder_amd/csrc/v224_hip.hip"
+
+template <int ABL>
+static double run15(int nlaunch, uint16_t *m0, uint16_t *m1, uint32_t *rows, int nrows, uint8_t *syms, V224Dev *ds,
+                    uint32_t *rowmeta, hipStream_t st) {
+  hipFuncSetAttribute((const void *)k_acs_lds15<ABL, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES);
+  hipFuncSetAttribute((const void *)k_acs_lds15<ABL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES);
+  k_init<<<V224_NSTATES / 8 / 256, 256, 0, st>>>(m0, 0, ds, rowmeta, nrows);
+  k_init_start<<<1, 1, 0, st>>>(m0, 0);
+  uint16_t *m[2] = { m0, m1 };
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  auto go = [&](int n, unsigned pass0) {
+    for (int i = 0; i < n; i++) {
+      unsigned pass = pass0 + i; int row0 = (int)((pass * 15) % (unsigned)nrows);
+      const uint8_t *sy = syms + 2 * ((pass * 15) % 4000);
+      if (pass & 1) k_acs_lds15<ABL, false, true><<<256, 1024, L15_LDS_BYTES, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, nrows, sy, ds, pass, rowmeta);
+      else k_acs_lds15<ABL, true, false><<<256, 1024, L15_LDS_BYTES, st>>>(m[pass & 1], m[(pass & 1) ^ 1], rows, row0, nrows, sy, ds, pass, rowmeta);
+    }
+  };
+  go(50, 0); hipStreamSynchronize(st);
+  hipEventRecord(a, st); go(nlaunch, 50); hipEventRecord(b, st); hipStreamSynchronize(st);
+  float ms = 0; hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a); hipEventDestroy(b);
+  return ms * 1e3 / nlaunch;
+}
+
+int main(int argc, char **argv) {
+  int nlaunch = argc > 1 ? atoi(argv[1]) : 400;
+  hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  uint8_t *arena; uint32_t *rows, *rowmeta; uint8_t *syms; V224Dev *ds;
+  int nrows = 600;
+  const size_t MiB = 1 << 20;
+  hipMalloc(&arena, 112 * MiB);
+  hipMalloc(&rows, (size_t)nrows * V224_ROWWORDS * 4); hipMalloc(&rowmeta, nrows * 4);
+  hipMalloc(&syms, 8192 + 64); hipMalloc(&ds, sizeof(V224Dev));
+  std::vector<uint8_t> h(8192 + 64);
+  for (size_t i = 0; i < h.size(); i++) h[i] = (uint8_t)(rand() & 0xff);
+  hipMemcpy(syms, h.data(), h.size(), hipMemcpyHostToDevice);
+  uint8_t *base = (uint8_t *)(((uintptr_t)arena + 16 * MiB - 1) & ~(uintptr_t)(16 * MiB - 1));
+  printf("arena %p base %p rows %p\n", (void *)arena, (void *)base, (void *)rows);
+  printf("memory-only us (rows: m0 offset MiB mod 16, cols: m1 offset)\n      ");
+  for (int b = 0; b < 16; b += 2) printf("%6d", b);
+  printf("\n");
+  for (int a = 0; a < 16; a += 2) {
+    printf("%4d: ", a);
+    for (int b = 0; b < 16; b += 2) {
+      uint16_t *m0 = (uint16_t *)(base + a * MiB), *m1 = (uint16_t *)(base + 48 * MiB + b * MiB);
+      printf("%6.2f", run15<1>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
+    }
+    printf("\n");
+  }
+  printf("full launch us\n");
+  for (int a = 0; a < 16; a += 4) {
+    printf("%4d: ", a);
+    for (int b = 0; b < 16; b += 2) {
+      uint16_t *m0 = (uint16_t *)(base + a * MiB), *m1 = (uint16_t *)(base + 48 * MiB + b * MiB);
+      printf("%6.2f", run15<0>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
+    }
+    printf("\n");
+  }
+  return 0;
+}

@@ -71,6 +71,52 @@ __global__ __launch_bounds__(256) void k_alt_pkadd_and(unsigned *out, unsigned s
   unsigned r = 0; for (int k = 0; k < 8; k++) r ^= a[k] ^ c[k];
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }
+// a whole packed butterfly written with VOP2 / SDWA instructions only (no VOP3P): 4 add, 2 sub, 4 half-word min,
+// then and / shift / or for the decision bits = 16 instructions
+__global__ __launch_bounds__(256) void k_bfly_vop2(unsigned *out, unsigned seed) {
+  unsigned a[8], b = seed | 3, c = seed * 7 + 1, acc = 0;
+  for (int k = 0; k < 8; k++) a[k] = threadIdx.x * (k + 3) + seed;
+  for (int i = 0; i < ITER; i++) {
+    asm volatile("v_add_u32 %2, %0, %9\n v_add_u32 %3, %1, %10\n v_add_u32 %4, %0, %10\n v_add_u32 %5, %1, %9\n"
+                 "v_sub_u32 %6, %2, %3\n v_sub_u32 %7, %4, %5\n"
+                 "v_min_u16_sdwa %0, %2, %3 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n"
+                 "v_min_u16_sdwa %0, %2, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
+                 "v_min_u16_sdwa %1, %4, %5 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n"
+                 "v_min_u16_sdwa %1, %4, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
+                 "v_and_b32 %6, %6, %9\n v_and_b32 %7, %7, %9\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 2, %7\n"
+                 "v_or_b32 %8, %8, %6\n v_or_b32 %8, %8, %7\n"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc) : "v"(b), "v"(c));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7] ^ acc;
+}
+// the same butterfly as the kernels have it: VOP3P arithmetic, perm / shift / bfi decisions = 13 instructions (+3 pad adds)
+__global__ __launch_bounds__(256) void k_bfly_pk(unsigned *out, unsigned seed) {
+  unsigned a[8], b = seed | 3, c = seed * 7 + 1, acc = 0;
+  for (int k = 0; k < 8; k++) a[k] = threadIdx.x * (k + 3) + seed;
+  for (int i = 0; i < ITER; i++) {
+    asm volatile("v_pk_add_u16 %2, %0, %9\n v_pk_add_u16 %3, %1, %10\n v_pk_add_u16 %4, %0, %10\n v_pk_add_u16 %5, %1, %9\n"
+                 "v_pk_sub_i16 %6, %2, %3\n v_pk_sub_i16 %7, %4, %5\n"
+                 "v_pk_min_u16 %0, %2, %3\n v_pk_min_u16 %1, %4, %5\n"
+                 "v_perm_b32 %6, %7, %6, %9\n v_lshrrev_b32 %8, 1, %8\n v_bfi_b32 %8, %10, %6, %8\n"
+                 "v_pk_add_u16 %2, %0, %9\n v_pk_add_u16 %3, %1, %10\n v_pk_add_u16 %4, %0, %10\n v_pk_add_u16 %5, %1, %9\n v_pk_sub_i16 %6, %2, %3\n"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc) : "v"(b), "v"(c));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7] ^ acc;
+}
+// VOP2 adds / subs with VOP3P min (the LDS8_PK = 0 mix)
+__global__ __launch_bounds__(256) void k_bfly_mixed(unsigned *out, unsigned seed) {
+  unsigned a[8], b = seed | 3, c = seed * 7 + 1, acc = 0;
+  for (int k = 0; k < 8; k++) a[k] = threadIdx.x * (k + 3) + seed;
+  for (int i = 0; i < ITER; i++) {
+    asm volatile("v_add_u32 %2, %0, %9\n v_add_u32 %3, %1, %10\n v_add_u32 %4, %0, %10\n v_add_u32 %5, %1, %9\n"
+                 "v_sub_u32 %6, %2, %3\n v_sub_u32 %7, %4, %5\n"
+                 "v_pk_min_u16 %0, %2, %3\n v_pk_min_u16 %1, %4, %5\n"
+                 "v_and_b32 %6, %6, %9\n v_and_b32 %7, %7, %9\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 2, %7\n"
+                 "v_or_b32 %8, %8, %6\n v_or_b32 %8, %8, %7\n v_add_u32 %2, %0, %9\n v_add_u32 %3, %1, %10\n"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(acc) : "v"(b), "v"(c));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7] ^ acc;
+}
 KERN(k_mix_pkadd_and, I_MIX_PKADD_AND) KERN(k_mix_pkadd_add, I_MIX_PKADD_ADD) KERN(k_mix_pkmin_shr, I_MIX_PKMIN_SHR)
 KERN(k_mix_bfi_and, I_MIX_BFI_AND) KERN(k_mix_pkadd_pkmin, I_MIX_PKADD_PKMIN) KERN(k_mix_add_and, I_MIX_ADD_AND)
 KERN(k_add, I_ADD) KERN(k_sub, I_SUB) KERN(k_pkadd, I_PKADD) KERN(k_pksub, I_PKSUB) KERN(k_pkmin, I_PKMIN)
@@ -93,6 +139,7 @@ template <typename F> static void run(const char *name, F kern, unsigned *out) {
 int main() {
   unsigned *out; hipMalloc(&out, 256 * 8 * 256 * 4 * 4);
 #define R(n) run(#n, n, out);
+  R(k_bfly_vop2) R(k_bfly_pk) R(k_bfly_mixed)
   R(k_grp_pkadd_and) R(k_alt_pkadd_and)
   R(k_mix_pkadd_and) R(k_mix_pkadd_add) R(k_mix_pkmin_shr) R(k_mix_bfi_and) R(k_mix_pkadd_pkmin) R(k_mix_add_and)
   R(k_add) R(k_sub) R(k_pkadd) R(k_pksub) R(k_pkmin) R(k_pkshr) R(k_pkmad) R(k_shr) R(k_and) R(k_bfi) R(k_andor)
