@@ -274,12 +274,15 @@ def main():
         steps_per_launch = steps_timed / launches if launches else 0
         ach = ALG_BYTES_PER_STEP * steps_per_launch / (avg_ms * 1e-3) / 1e9 if launches else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         kern = {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8", 3: "k_acs_lds15"}[eng]
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("kernel") == kern:       # PMC passes cannot share a run with the timing: committed constant
-                traffic = tj["hbm_bytes_per_launch"]
+        tsrc = None
+        for tname in ("r01c_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("kernel") == kern:   # PMC passes cannot share a run with the timing: committed constant
+                    traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + tname
+                    break
         res = {
             "metric": "Viterbi K=24 Msymbols/s",
             "value": round(total_syms / dt / 1e6, 4), "unit": "Msymbols/s",
@@ -295,7 +298,7 @@ def main():
                        "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tsrc,
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_STEP * steps_per_launch),
                          "kernel": kern,
                          "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
