@@ -45,6 +45,14 @@ int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, ui
 int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbits, int delay, uint8_t *d_out);
 int v224hip_stream_chunk(void *p);                 /* bits per internal chunk (option "chunk") */
 
+/* A batch of independent frames, each decoded as vtest224.c:116-118 / decode.c:220-222 do it:
+ *   init_viterbi224(d, startstate); update_viterbi224_blk(d, syms + f*2*framebits, framebits);
+ *   chainback_viterbi224(d, out + f*((framebits+7)/8), framebits, endstate);
+ * Frame f runs on decoders[f % ndec] (each created with len >= framebits, all on one device); with ndec = 2 the
+ * frames overlap on the GPU.  Host buffers.  0, or -1 (v224hip_last_error()). */
+int v224hip_decode_frames(void *const *decoders, int ndec, const uint8_t *syms, int nframes, int framebits,
+                          int startstate, unsigned int endstate, uint8_t *out);
+
 /* Generic option setter: "chunk" (bits per stream chunk), "profile" (N > 0: bracket every Nth run of back-to-back
  * ACS launches -- one stream chunk or one update call -- with a HIP event pair on the decoder's
  * stream).  -1 on unknown key / bad value. */

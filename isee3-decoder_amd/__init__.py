@@ -30,7 +30,7 @@ V224_SYMBOLS = [
     "decodebit_viterbi224", "decodeword_viterbi224",
     "v224hip_device_count", "v224hip_set_device", "v224hip_create", "v224hip_last_error",
     "v224hip_update_dev", "v224hip_stream_decode", "v224hip_stream_decode_dev",
-    "v224hip_stream_chunk", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
+    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
     "v224hip_export_row", "v224hip_export_metrics", "v224hip_dev_alloc", "v224hip_dev_free",
     "v224hip_h2d", "v224hip_d2h",
 ]
@@ -78,6 +78,8 @@ def v224_lib():
     L.v224hip_stream_decode.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p]
     L.v224hip_stream_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.v224hip_stream_chunk.argtypes = [C.c_void_p]
+    L.v224hip_decode_frames.argtypes = [C.POINTER(C.c_void_p), C.c_int, u8p, C.c_int, C.c_int, C.c_int,
+                                        C.c_uint, u8p]
     L.v224hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     L.v224hip_sync.argtypes = [C.c_void_p]
     L.v224hip_acs_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double),
@@ -249,6 +251,22 @@ DSP_SYMBOLS = [
     "pmd_get_spectrum",
 ]
 
+
+
+def decode_frames(decoders, syms, nframes, framebits, startstate=0, endstate=0):
+    """v224hip_decode_frames: `nframes` independent frames (init / update(framebits) / chainback each, as
+    vtest224.c:116-118 and decode.c:220-222 do), frame f on decoders[f % len(decoders)].  Returns
+    uint8[nframes, ceil(framebits/8)]."""
+    L = v224_lib()
+    syms = np.ascontiguousarray(syms, dtype=np.uint8)
+    assert syms.size >= 2 * framebits * nframes
+    out = np.zeros((nframes, (framebits + 7) // 8), dtype=np.uint8)
+    hs = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+    rc = L.v224hip_decode_frames(hs, len(decoders), syms.ctypes.data_as(u8p), int(nframes), int(framebits),
+                                 int(startstate), int(endstate) & 0xFFFFFFFF, out.ctypes.data_as(u8p))
+    if rc != 0:
+        raise RuntimeError("v224hip_decode_frames: " + L.v224hip_last_error().decode())
+    return out
 
 class PmdPeak(C.Structure):
     _fields_ = [("peak", C.c_int), ("maxenergy", C.c_double), ("peak_re", C.c_double), ("peak_im", C.c_double),

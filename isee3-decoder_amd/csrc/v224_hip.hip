@@ -767,6 +767,52 @@ fail:
   return -1;
 }
 
+// ---- batch of independent frames ------------------------------------------------------------
+// Frame f goes to decoder f % ndec; every decoder works on its own stream, so with two decoders one frame's
+// passes run under the other's (two LDS15 workgroups fit a CU) and a frame's traceback runs under the next
+// frame's ACS.  Nothing synchronises with the host until all frames are enqueued.
+extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint8_t *syms, int nframes,
+                                     int framebits, int startstate, unsigned int endstate, uint8_t *out) {
+  uint8_t *d_syms = nullptr, *d_out = nullptr;
+  if (!decoders || ndec <= 0 || nframes < 0 || framebits <= 0 || !syms || !out) {
+    snprintf(g_err, sizeof g_err, "decode_frames: bad argument");
+    return -1;
+  }
+  if (nframes == 0) return 0;
+  {
+    const size_t symbytes = 2 * (size_t)framebits, outbytes = ((size_t)framebits + 7) / 8;
+    V224 *v0 = (V224 *)decoders[0];
+    for (int i = 0; i < ndec; i++) {
+      V224 *v = (V224 *)decoders[i];
+      if (!v || v->len < framebits || v->dev != v0->dev) {
+        snprintf(g_err, sizeof g_err, "decode_frames: decoder %d is NULL, shorter than a frame or on another device", i);
+        return -1;
+      }
+    }
+    HIPCHK(hipSetDevice(v0->dev));
+    HIPCHK(hipMalloc(&d_syms, symbytes * nframes));
+    HIPCHK(hipMalloc(&d_out, outbytes * nframes));
+    HIPCHK(hipMemcpy(d_syms, syms, symbytes * nframes, hipMemcpyHostToDevice));
+    for (int i = 0; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
+    for (int f = 0; f < nframes; f++) {
+      V224 *v = (V224 *)decoders[f % ndec];
+      if (init_viterbi224(v, startstate) != 0) goto fail;
+      if (enqueue_acs(v, d_syms + symbytes * f, framebits) != 0) goto fail;
+      k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f);
+    }
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
+    HIPCHK(hipMemcpy(out, d_out, outbytes * nframes, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_syms); (void)hipFree(d_out);
+  return 0;
+fail:
+  for (int i = 0; i < ndec; i++) if (decoders[i]) (void)hipStreamSynchronize(((V224 *)decoders[i])->st);
+  if (d_syms) (void)hipFree(d_syms);
+  if (d_out) (void)hipFree(d_out);
+  return -1;
+}
+
 static int metric_extreme(V224 *v, int want_max, long long *out) {
   unsigned *d = (unsigned *)(v->dmisc + 256);
   unsigned h[2]; long long off;

@@ -22,3 +22,10 @@ for rep in range(4):
     a = d.chainback(nb, 0); b = d2.chainback(nb, 0)
 t1 = time.perf_counter()
 print("2 decoders x 4 frames: %.3f ms per frame" % ((t1-t0)*1e3/8))
+# batch entry point: 32 frames over 1, 2, 3 decoders
+d3 = pkg.Viterbi224(nb)
+frames = np.tile(syms[:2 * nb], 32)
+for decs in ([d], [d, d2], [d, d2, d3]):
+    pkg.decode_frames(decs, frames, 4, nb)
+    t0 = time.perf_counter(); out = pkg.decode_frames(decs, frames, 32, nb); t1 = time.perf_counter()
+    print("decode_frames, %d decoder(s): %.3f ms per 1024-bit frame = %.3f Msymbols/s" % (len(decs), (t1 - t0) * 1e3 / 32, 32 * 2 * nb / (t1 - t0) / 1e6))

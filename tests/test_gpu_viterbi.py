@@ -269,3 +269,65 @@ def test_config1_framed_frames_vs_oracle(pkg, dist):
         assert np.array_equal(d.chainback(framebits, 0), o.chainback(framebits, 0)), "frame %d" % f
     d.close()
     o.close()
+
+
+def test_decode_frames_batch_on_two_decoders(pkg):
+    """v224hip_decode_frames: 7 independent 1000-bit frames (vtest224.c:116-118 per frame) spread over two
+    decoders on two streams -- every frame's bytes equal to the oracle's, for a non-zero start / end state too."""
+    framebits, nframes = 1000, 7
+    frames = []
+    for f in range(nframes):
+        if f % 3 == 2:
+            frames.append(orc.gen_uniform(7300 + f, 2 * framebits))
+        else:
+            frames.append(orc.gen_coded_frame(7200 + f, framebits, 2.5, 24.0)[0])
+    syms = np.concatenate(frames)
+    o = orc.OracleV224(framebits, orc.FAST)
+    decs = [pkg.Viterbi224(framebits), pkg.Viterbi224(framebits)]
+    for start, end in ((0, 0), (0x819fbe, 0x2aaaaa)):
+        want = []
+        for f in range(nframes):
+            o.init(start)
+            o.update(frames[f], framebits)
+            want.append(o.chainback(framebits, end))
+        got = pkg.decode_frames(decs, syms, nframes, framebits, start, end)
+        assert np.array_equal(got, np.stack(want))
+        one = pkg.decode_frames(decs[:1], syms, nframes, framebits, start, end)     # one decoder: same answer
+        assert np.array_equal(one, got)
+    # the decoders are still good for the ordinary API afterwards
+    decs[0].init(0)
+    decs[0].update(frames[0], framebits)
+    o.init(0); o.update(frames[0], framebits)
+    assert np.array_equal(decs[0].chainback(framebits, 0), o.chainback(framebits, 0))
+    with pytest.raises(RuntimeError):
+        pkg.decode_frames(decs, syms, nframes - 1, framebits + 1)  # ring shorter than a frame
+    for d in decs:
+        d.close()
+    o.close()
+
+
+def test_two_decoders_interleaved_streams(pkg):
+    """Two LDS15 decoders share the CUs when driven alternately (bench.py --segments-per-gpu 2): both streams
+    still decode exactly as a lone decoder does."""
+    nbits, delay = 20_400, 200
+    streams = [orc.gen_coded_stream(9300 + i, nbits, 2.5, 24.0, 5)[0] for i in range(2)]
+    lone = []
+    for sy in streams:
+        d = pkg.Viterbi224(delay + 2 * 1020)
+        d.init(0)
+        lone.append(d.stream_decode(sy, delay))
+        d.close()
+    decs = [pkg.Viterbi224(delay + 2 * 1020) for _ in range(2)]
+    dsy = [pkg.DeviceBuffer.from_numpy(sy) for sy in streams]
+    dout = [pkg.DeviceBuffer(nbits) for _ in range(2)]
+    for d in decs:
+        d.init(0)
+    slab = 4 * 1020
+    for pos in range(0, nbits, slab):
+        n = min(slab, nbits - pos)
+        for i in range(2):
+            decs[i].stream_decode_dev(dsy[i], n, delay, dout[i], sym_offset=2 * pos, out_offset=pos)
+    for i in range(2):
+        decs[i].sync()
+        assert np.array_equal(dout[i].to_numpy(np.uint8), lone[i])
+        decs[i].close()
