@@ -299,6 +299,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tsrc,
+                         "physical_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and launches) else None,
+                         "note": "algorithmic bytes (SURVEY 8d: 34 603 008 B per trellis step) exceed the physical traffic "
+                                 "because one launch carries the metrics through several steps; the launch itself is "
+                                 "VALU-issue bound, see DESIGN.md section 3",
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_STEP * steps_per_launch),
                          "kernel": kern,
                          "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
