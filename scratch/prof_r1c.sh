@@ -3,7 +3,7 @@
 # (2) PMC passes (one counter group per run, kernel-trace only) on a short run
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-OUT=gpurun_out/prof_r1c; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/prof_r1e; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || { echo "trace run failed"; tail -5 $OUT/bench_under_rocprof.err; exit 1; }
 find $OUT/trace -name "*kernel_trace.csv" -delete
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do head -6 $f; done
