@@ -14,6 +14,7 @@ reference's own code run here:
   * vdecode_cli.npz      oracle/_ref/vdecode_port_ref (vdecode.c unmodified) stdout, incl. a forced
                          phase flip, the -p start phase and -F.
   * symdemod_cli.npz     oracle/_ref/symdemod_ref (symdemod.c unmodified) stdout.
+  * decode_cli2.npz      the same driver through a noise burst (lock lost) and a 3-symbol slip, also with -n -r 512
   * decode_cli.npz       oracle/_ref/decode_port_ref (decode.c -V unmodified, port decoder) stdout: frame-sync
                          correlator + init(0x819fbe)/update(1024)/chainback per frame.
   * pmdemod_oracle.npz   NOT from the reference (FFTW3 absent => pmdemod.c cannot be built): outputs
@@ -180,6 +181,32 @@ def make_decode():
     print(out.decode(errors="replace")[:600])
 
 
+def _decode_case(spec):
+    name, args, syms = spec
+    return name, args, syms, orc.ref_cli("decode_port_ref", args, syms.tobytes())
+
+
+def make_decode2():
+    """More of decode.c -V: a noise burst (bad frame, lock lost, the correlator searches again) and a symbol
+    slip (the next sync is found at a new offset), with and without -n / -r."""
+    sy, _ = _tlm_symbols(611, 9 * 1024 + 300, 5.0)
+    rng = np.random.default_rng(612)
+    hurt = sy.copy()
+    hurt[3 * 2048 + 700:4 * 2048 + 300] = rng.integers(0, 256, 2048 - 400, dtype=np.uint8)   # burst inside frames 4/5
+    hurt = np.concatenate([hurt[:6 * 2048 + 911], hurt[6 * 2048 + 914:]])                     # three symbols lost
+    specs = [("slip_noise", ["-V"], hurt), ("slip_noise_nobad_r512", ["-V", "-n", "-r", "512"], hurt)]
+    with mp.Pool(len(specs)) as pool:
+        res = pool.map(_decode_case, specs)
+    flat = {"names": np.array([r[0] for r in res])}
+    for name, args, syms, out in res:
+        flat[name + "/args"] = np.array(args, dtype="U8")
+        flat[name + "/syms"] = syms
+        flat[name + "/stdout"] = np.frombuffer(out, dtype=np.uint8)
+        print("decode2", name, len(syms), "symbols ->", len(out), "bytes")
+        print(out.decode(errors="replace")[:300])
+    np.savez_compressed(os.path.join(HERE, "decode_cli2.npz"), **flat)
+
+
 def make_symdemod():
     cases = [
         # name, args, generator kwargs
@@ -238,7 +265,7 @@ def make_pmdemod():
 
 
 ALL = dict(framed=make_framed, stream=make_stream, vdecode=make_vdecode, symdemod=make_symdemod,
-           pmdemod=make_pmdemod, decode=make_decode)
+           pmdemod=make_pmdemod, decode=make_decode, decode2=make_decode2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

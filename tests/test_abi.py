@@ -63,7 +63,7 @@ def test_dsp_header_vs_library():
 
 def test_cli_binaries_built():
     pkg = load_pkg()
-    for exe in ("vdecode", "symdemod", "pmdemod"):
+    for exe in ("vdecode", "symdemod", "pmdemod", "decode"):
         assert os.access(pkg.cli_path(exe), os.X_OK)
 
 

@@ -53,3 +53,23 @@ def test_reference_decode_source_on_hip_library():
     got, want = body(p.stdout), body(z["stdout"].tobytes())
     assert got == want
     assert any(l.endswith(b"12 fc 81 9f be") for l in got) and sum(l.startswith(b"Frame ") for l in got) >= 3
+
+
+# ---- the product's own framed stage (isee3-decoder_amd/bin/decode) --------------------------
+def _decode_cases():
+    import test_decode_host
+    return test_decode_host.cases()
+
+
+@pytest.mark.parametrize("case", _decode_cases(), ids=lambda c: c[0])
+def test_decode_stage_byte_exact(case):
+    """bin/decode -V (frame sync + batches of frames through v224hip_decode_frames on two decoders) prints exactly
+    what the reference's decode.c -V printed on the port decoder, lost lock and symbol slip included."""
+    import test_decode_host
+    from conftest import load_pkg
+    name, args, syms, want = case
+    exe = load_pkg().cli_path("decode")
+    p = test_decode_host.run_as(exe, test_decode_host.argv0_of(want), args + ["-v"], syms.tobytes(), timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == want
+    assert b"batches" in p.stderr
