@@ -331,3 +331,30 @@ def test_two_decoders_interleaved_streams(pkg):
         decs[i].sync()
         assert np.array_equal(dout[i].to_numpy(np.uint8), lone[i])
         decs[i].close()
+
+
+@pytest.mark.parametrize("length", [17, 31, 64])
+def test_lds15_ragged_updates_small_ring(pkg, length):
+    """update calls of every residue mod 15 on rings that a 15-step pass has to wrap (and that an update laps
+    several times): after every call ALL ring rows, a traceback and the metrics equal the oracle's."""
+    sizes = [15, 30, 1, 16, 45, 7, 29, 15, 14, 61]
+    syms = orc.gen_uniform(7400 + length, 2 * sum(sizes))
+    d = pkg.Viterbi224(length, 3, 0)
+    o = orc.OracleV224(length, orc.FAST)
+    d.init(3)
+    o.init(3)
+    pos = 0
+    for n in sizes:
+        d.update(syms[2 * pos:2 * (pos + n)], n)
+        o.update(syms[2 * pos:2 * (pos + n)], n)
+        pos += n
+        for r in range(length):
+            assert _fnv(d.export_row(r)) == o.row_hash(r), "row %d after %d steps" % (r, pos)
+        dl = min(length - 1, 13)
+        assert d.decodebit(dl, 0) == o.decodebit(dl, 0)
+        assert d.decodebit(dl, -1) == o.decodebit(dl, -1)
+    m = d.export_metrics()
+    for st in (0, 3, 255, 256, 32767, 32768, 0x555555, (1 << 23) - 1):
+        assert int(m[st]) == o.metric_rel(st)
+    d.close()
+    o.close()
