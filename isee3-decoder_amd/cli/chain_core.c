@@ -53,8 +53,60 @@ static int vd_init(void *h, int s) { return init_viterbi224(h, s); }
 static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) { return v224hip_stream_decode(h, s, n, d, o); }
 static void vd_destroy(void *h) { delete_viterbi224(h); }
 
+/* ---- in-memory channel pmdemod -> symdemod: a byte ring with read(2) semantics on one side and a stdio stream
+ * (fopencookie) on the other; a pipe costs two kernel copies and a syscall per 64 KiB of a 2 B/sample stream ---- */
+typedef struct {
+  pthread_mutex_t mu; pthread_cond_t can_read, can_write;
+  unsigned char *buf; size_t cap, head, count; int closed, reader_gone;
+} chan;
+static chan *chan_new(size_t cap) {
+  chan *c = calloc(1, sizeof *c);
+  if (!c) return NULL;
+  c->buf = malloc(cap); c->cap = cap;
+  if (!c->buf) { free(c); return NULL; }
+  pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->can_read, NULL); pthread_cond_init(&c->can_write, NULL);
+  return c;
+}
+static void chan_free(chan *c) { if (c) { free(c->buf); free(c); } }
+static ssize_t chan_write(void *p, const char *b, size_t n) {
+  chan *c = p; size_t done = 0;
+  pthread_mutex_lock(&c->mu);
+  while (done < n) {
+    while (c->count == c->cap && !c->reader_gone) pthread_cond_wait(&c->can_write, &c->mu);
+    if (c->reader_gone) { pthread_mutex_unlock(&c->mu); return 0; }      /* like EPIPE: the stream goes into error */
+    size_t tail = (c->head + c->count) % c->cap, room = c->cap - c->count;
+    size_t k = n - done < room ? n - done : room;
+    if (k > c->cap - tail) k = c->cap - tail;
+    memcpy(c->buf + tail, b + done, k);
+    c->count += k; done += k;
+    pthread_cond_signal(&c->can_read);
+  }
+  pthread_mutex_unlock(&c->mu);
+  return (ssize_t)n;
+}
+static int chan_close(void *p) {
+  chan *c = p;
+  pthread_mutex_lock(&c->mu); c->closed = 1; pthread_cond_broadcast(&c->can_read); pthread_mutex_unlock(&c->mu);
+  return 0;
+}
+static long chan_read(void *p, void *b, unsigned long n) {       /* whole int16 samples only */
+  chan *c = p;
+  pthread_mutex_lock(&c->mu);
+  while (c->count < 2 && !c->closed) pthread_cond_wait(&c->can_read, &c->mu);
+  size_t k = c->count & ~(size_t)1;
+  if (k > (n & ~1ul)) k = n & ~1ul;
+  if (k > c->cap - c->head) k = (c->cap - c->head) & ~(size_t)1;
+  if (k == 0 && c->count >= 2) {                                   /* a sample straddles the wrap: hand it over alone */
+    unsigned char *o = b; o[0] = c->buf[c->head]; o[1] = c->buf[(c->head + 1) % c->cap]; k = 2;
+  } else memcpy(b, c->buf + c->head, k);
+  c->head = (c->head + k) % c->cap; c->count -= k;
+  pthread_cond_signal(&c->can_write);
+  pthread_mutex_unlock(&c->mu);
+  return (long)k;
+}
+
 typedef struct { pmdemod_opts o; FILE *in, *out; int rc; } pm_arg;
-typedef struct { symdemod_opts o; int fd_in; FILE *out; int rc; } sy_arg;
+typedef struct { symdemod_opts o; chan *in; FILE *out; int rc; } sy_arg;
 typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; } vd_arg;
 
 static void *pm_thread(void *p) {
@@ -67,9 +119,9 @@ static void *pm_thread(void *p) {
 static void *sy_thread(void *p) {
   sy_arg *a = p;
   symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy };
-  a->rc = symdemod_run(&a->o, &e, a->fd_in, a->out, stderr);
+  a->rc = symdemod_run_rd(&a->o, &e, chan_read, a->in, a->out, stderr);
   fclose(a->out);
-  close(a->fd_in);
+  pthread_mutex_lock(&a->in->mu); a->in->reader_gone = 1; pthread_cond_broadcast(&a->in->can_write); pthread_mutex_unlock(&a->in->mu);
   return NULL;
 }
 static void *vd_thread(void *p) {
@@ -93,7 +145,9 @@ void isee3_chain_default_opts(isee3_chain_opts *o) {
 
 static int chain_run(const isee3_chain_opts *co, FILE *in, FILE *out) {
   pm_arg pa; sy_arg sa; vd_arg va;
-  int p1[2], p2[2];
+  int p2[2];
+  chan *c1 = chan_new((size_t)64 << 20);
+  cookie_io_functions_t cio = { NULL, chan_write, NULL, chan_close };
   pmdemod_default_opts(&pa.o); symdemod_default_opts(&sa.o); vdecode_default_opts(&va.o);
   pa.o.argv0 = "isee3chain/pmdemod"; sa.o.argv0 = "isee3chain/symdemod"; va.o.argv0 = "isee3chain/vdecode";
   pa.o.samprate = co->samprate; sa.o.samprate = (int)co->samprate;
@@ -109,18 +163,19 @@ static int chain_run(const isee3_chain_opts *co, FILE *in, FILE *out) {
   pa.o.quiet = sa.o.quiet = va.o.quiet = !co->verbose;
   if (getenv("V224HIP_CHUNK")) g_chunk = atoi(getenv("V224HIP_CHUNK"));
   if (g_chunk < 8) g_chunk = 1020;
-  if (pipe(p1) || pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() failed"); return 2; }
+  if (!c1 || pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() / channel allocation failed"); chan_free(c1); return 2; }
 #ifdef F_SETPIPE_SZ
-  fcntl(p1[1], F_SETPIPE_SZ, 1 << 20); fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);
+  fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);
 #endif
-  pa.in = in; pa.out = fdopen(p1[1], "w");
-  sa.fd_in = p1[0]; sa.out = fdopen(p2[1], "w");
+  pa.in = in; pa.out = fopencookie(c1, "w", cio);
+  sa.in = c1; sa.out = fdopen(p2[1], "w");
   va.fd_in = p2[0]; va.out = out;
   pthread_t t1, t2, t3;
   pthread_create(&t1, NULL, pm_thread, &pa);
   pthread_create(&t2, NULL, sy_thread, &sa);
   pthread_create(&t3, NULL, vd_thread, &va);
   pthread_join(t1, NULL); pthread_join(t2, NULL); pthread_join(t3, NULL);
+  chan_free(c1);
   if (pa.rc || sa.rc || va.rc) {
     snprintf(g_chain_err, sizeof g_chain_err, "stage failed (pmdemod %d, symdemod %d, vdecode %d): %.80s / %.80s", pa.rc, sa.rc,
              va.rc, isee3dsp_last_error(), v224hip_last_error());
@@ -137,35 +192,13 @@ int isee3_chain_run_fd(const isee3_chain_opts *o, int fd_in, int fd_out) {
   return rc;
 }
 
-typedef struct { const int16_t *iq; size_t bytes; int fd; } feed_arg;
-static void *feed_thread(void *p) {
-  feed_arg *f = p;
-  const char *b = (const char *)f->iq;
-  size_t done = 0;
-  while (done < f->bytes) {
-    ssize_t w = write(f->fd, b + done, f->bytes - done > (1u << 20) ? (1u << 20) : f->bytes - done);
-    if (w <= 0) break;
-    done += (size_t)w;
-  }
-  close(f->fd);
-  return NULL;
-}
-
 int isee3_chain_run_mem(const isee3_chain_opts *o, const int16_t *iq, size_t nsamples, char *out, size_t cap, size_t *nout) {
-  int pin[2];
-  if (pipe(pin)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() failed"); return 2; }
-#ifdef F_SETPIPE_SZ
-  fcntl(pin[1], F_SETPIPE_SZ, 1 << 20);
-#endif
-  FILE *in = fdopen(pin[0], "r");
+  FILE *in = fmemopen((void *)iq, nsamples * 4, "r");       /* the capture is read where it lies */
   FILE *mo = fmemopen(out, cap, "w");
-  if (!in || !mo) { snprintf(g_chain_err, sizeof g_chain_err, "fdopen/fmemopen failed"); return 2; }
+  if (!in || !mo) { snprintf(g_chain_err, sizeof g_chain_err, "fmemopen failed"); return 2; }
+  setvbuf(in, NULL, _IOFBF, 1 << 20);                /* (unbuffered, glibc reads a memory stream byte by byte) */
   setvbuf(mo, NULL, _IONBF, 0);                       /* write straight into the caller's buffer */
-  feed_arg fa = { iq, nsamples * 4, pin[1] };
-  pthread_t tf;
-  pthread_create(&tf, NULL, feed_thread, &fa);
   int rc = chain_run(o, in, mo);
-  pthread_join(tf, NULL);
   long pos = ftell(mo);
   fclose(mo); fclose(in);
   if (nout) *nout = pos > 0 ? (size_t)pos : 0;

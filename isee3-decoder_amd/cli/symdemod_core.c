@@ -97,7 +97,12 @@ static int timesearch(ctx_t *c, int *symphase, int firstsample, double symbolsam
   return 0;
 }
 
+static long fd_reader(void *ctx, void *buf, unsigned long nbytes) { return (long)read(*(int *)ctx, buf, nbytes); }
 int symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, FILE *out, FILE *err) {
+  return symdemod_run_rd(o, e, fd_reader, &fd_in, out, err);
+}
+
+int symdemod_run_rd(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader rd, void *rctx, FILE *out, FILE *err) {
   fesetround(FE_TONEAREST);                          /* symdemod.c:48 */
   int Samprate = o->samprate;
   double Symrate = o->symrate, window = o->window;
@@ -125,9 +130,9 @@ int symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, FI
       nsamples -= slide; firstsample -= slide; total_samples += slide;
     }
     while (nsamples < fullwater) {
-      ssize_t cnt = read(fd_in, samples + nsamples, sizeof(*samples) * (size_t)(fullwater - nsamples));
+      long cnt = rd(rctx, samples + nsamples, sizeof(*samples) * (unsigned long)(fullwater - nsamples));
       if (cnt <= 0) break;
-      nsamples += (int)(cnt / (ssize_t)sizeof(*samples));
+      nsamples += (int)(cnt / (long)sizeof(*samples));
     }
     if (nsamples < window * Samprate) break;
 

@@ -29,4 +29,8 @@ typedef struct {
 void symdemod_default_opts(symdemod_opts *o);
 int  symdemod_parse_args(symdemod_opts *o, int argc, char **argv);
 int  symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, FILE *out, FILE *err);
+/* the same stage reading through rd(ctx, buf, nbytes) (read(2) semantics: > 0 bytes, 0 at end of input) instead
+ * of a file descriptor -- the in-process chain hands blocks over in memory */
+typedef long (*symdemod_reader)(void *ctx, void *buf, unsigned long nbytes);
+int  symdemod_run_rd(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader rd, void *rctx, FILE *out, FILE *err);
 #endif

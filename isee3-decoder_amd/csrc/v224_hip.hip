@@ -65,7 +65,6 @@ struct V224 {
   unsigned long long nsteps;// trellis steps since init
   unsigned pass;            // ACS launches since init (minima ping-pong index)
   bool min_valid;           // blkmin[pass & 1] describes the current metric buffer
-  float place_us_best, place_us_worst;   // place_metrics(): probe times of the chosen / the worst candidate
   int layout;               // 0: m[cur] is in natural state order; 1: in the L15 tile order (v224_lds15.hip.inc)
   bool fresh;               // nothing has run since init: m[cur] is uniform except at `start`
   unsigned start;
@@ -402,37 +401,35 @@ static int env_int(const char *name, int dflt) {
 // allocation lands in varies from process to process).  So: time the pass with its arithmetic compiled out
 // (template ABL = 1: same loads, LDS traffic and stores) on a few candidate partners for m[0], keep the fastest.
 static int place_metrics(V224 *v) {
-  const int NCAND = 6, NPROBE = 24;
+  const int NCAND = 6, NWARM = 4, NPROBE = 12;
   uint16_t *cand[NCAND] = {v->m[1], nullptr, nullptr, nullptr, nullptr, nullptr};
   float t[NCAND] = {0, 0, 0, 0, 0, 0};
   hipEvent_t a = nullptr, b = nullptr;
-  int best = 0, n = 1;
+  int best = 0, n = 0;
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-  for (; n < NCAND; n++)
-    if (hipMalloc(&cand[n], sizeof(uint16_t) * V224_NSTATES) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
-  for (int c = 0; c < n; c++) {
+  for (int c = 0; c < NCAND; c++) {
+    if (c > 0 && hipMalloc(&cand[c], sizeof(uint16_t) * V224_NSTATES) != hipSuccess) { (void)hipGetLastError(); cand[c] = nullptr; break; }
+    n = c + 1;
     uint16_t *m[2] = {v->m[0], cand[c]};
-    for (int rep = 0; rep < 2; rep++) {              // rep 0 warms up
-      HIPCHK(hipEventRecord(a, v->st));
-      for (int i = 0; i < NPROBE; i++) {
-        if (i & 1) k_acs_lds15<1, false, true><<<256, 1024, L15_LDS_BYTES, v->st>>>(m[1], m[0], v->rows, 0, v->len, v->dmisc, v->ds, (unsigned)i, v->rowmeta);
-        else       k_acs_lds15<1, true, false><<<256, 1024, L15_LDS_BYTES, v->st>>>(m[0], m[1], v->rows, 0, v->len, v->dmisc, v->ds, (unsigned)i, v->rowmeta);
-      }
-      HIPCHK(hipEventRecord(b, v->st));
-      HIPCHK(hipEventSynchronize(b));
-      HIPCHK(hipEventElapsedTime(&t[c], a, b));
+    for (int i = -NWARM; i < NPROBE; i++) {
+      if (i == 0) HIPCHK(hipEventRecord(a, v->st));
+      if (i & 1) k_acs_lds15<1, false, true><<<256, 1024, L15_LDS_BYTES, v->st>>>(m[1], m[0], v->rows, 0, v->len, v->dmisc, v->ds, (unsigned)i, v->rowmeta);
+      else       k_acs_lds15<1, true, false><<<256, 1024, L15_LDS_BYTES, v->st>>>(m[0], m[1], v->rows, 0, v->len, v->dmisc, v->ds, (unsigned)i, v->rowmeta);
     }
+    HIPCHK(hipEventRecord(b, v->st));
+    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventElapsedTime(&t[c], a, b));
     if (t[c] < t[best]) best = c;
+    // two classes only: as soon as one candidate is clearly faster than another, it is in the right one
+    float worst = t[0];
+    for (int k = 1; k <= c; k++) if (t[k] > worst) worst = t[k];
+    if (worst > 1.12f * t[best]) break;
   }
   v->m[1] = cand[best];
   for (int c = 0; c < n; c++) if (c != best) (void)hipFree(cand[c]);
   HIPCHK(hipMemsetAsync(v->rowmeta, 0, (size_t)v->len * sizeof(uint32_t), v->st));
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  v->place_us_best = t[best] * 1e3f / NPROBE;
-  v->place_us_worst = t[best];
-  for (int c = 0; c < n; c++) if (t[c] > v->place_us_worst) v->place_us_worst = t[c];
-  v->place_us_worst = v->place_us_worst * 1e3f / NPROBE;
   if (getenv("V224HIP_VERBOSE")) {
     fprintf(stderr, "v224hip: metric buffer placement, memory phases of a pass in us:");
     for (int c = 0; c < n; c++) fprintf(stderr, " %.2f%s", t[c] * 1e3f / NPROBE, c == best ? "*" : "");
