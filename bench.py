@@ -158,7 +158,7 @@ def chain_workload(a, rank, world, local, dist, torch, pkg, redev="cuda"):
             "scaling": "strong" if plan is not None else "weak",
             "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic",
             "config": {"workload": "pmdemod|symdemod|vdecode on %g s of %g kS/s int16 IQ, %g Hz bins, 1024 sym/s "
-                                   "Manchester, one capture per GPU, host memory -> pipe -> GPU included"
+                                   "Manchester, one capture per GPU, capture in host memory (H2D / D2H of every stage included)"
                                    % (a.chain_seconds, fs / 1e3, a.chain_bin), "decoded_bits": int(len(got)),
                        "segments": a.chain_segments, "warm_blocks": a.chain_warm_blocks if plan is not None else 0,
                        "seams": seams},

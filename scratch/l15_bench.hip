@@ -59,7 +59,9 @@ static double run15_dual(int nlaunch, uint16_t *m0, uint16_t *m1, uint16_t *n0, 
 
 int main(int argc, char **argv) {
   int nlaunch = argc > 1 ? atoi(argv[1]) : 2000;
-  hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  hipStream_t st;
+  if (getenv("L15_PRIO")) { int lo, hi; hipDeviceGetStreamPriorityRange(&lo, &hi); hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi); printf("high-priority stream (%d)\n", hi); }
+  else hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
   uint16_t *m0, *m1; uint32_t *rows, *rowmeta; uint8_t *syms; V224Dev *ds;
   int nrows = 1500;
   hipMalloc(&m0, V224_NSTATES * 2); hipMalloc(&m1, V224_NSTATES * 2);

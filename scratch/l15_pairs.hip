@@ -53,6 +53,8 @@ int main(int argc, char **argv) {
     }
     printf("\n");
   }
+  printf("in place (m1 == m0; timing only, racy by construction): memory-only %6.2f us, full %6.2f us\n",
+         run15<1>(nlaunch, buf[0], buf[0], rows, nrows, syms, ds, rowmeta, st), run15<0>(nlaunch, buf[0], buf[0], rows, nrows, syms, ds, rowmeta, st));
   printf("full launch: best pair (%d,%d) %6.2f us, worst pair (%d,%d) %6.2f us\n", bi, bj,
          run15<0>(nlaunch, buf[bi], buf[bj], rows, nrows, syms, ds, rowmeta, st), wi, wj,
          run15<0>(nlaunch, buf[wi], buf[wj], rows, nrows, syms, ds, rowmeta, st));
