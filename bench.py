@@ -177,6 +177,12 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--segments-per-gpu", type=int, default=1,
                     help="independent streams decoded concurrently on each GPU (own HIP streams)")
+    ap.add_argument("--split", type=int, default=2,
+                    help="> 1: decode each stream with this many decoders working on consecutive parts at the same time, "
+                         "verified at the seams (v224hip_stream_decode_split): same output as one decoder.  1: one "
+                         "decoder per stream.  With > 1 a single-decoder pass is timed too (1 step) and reported "
+                         "beside the headline, together with the check that both outputs are identical")
+    ap.add_argument("--split-warm", type=int, default=14280, help="warm-up bits before each part (14 chunks)")
     ap.add_argument("--cpu-bits", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", choices=["viterbi", "chain"], default="viterbi")
@@ -228,15 +234,19 @@ def main():
     segs = []
     for g in mine:
         syms, bits, noise_mask = synth.coded_stream(1000 + g, nbits, 3.0, 24.0, 1.0)
-        dec = pkg.Viterbi224(a.delay + 2 * chunk, a.engine, a.k)
-        dec.set_option("chunk", chunk)
-        segs.append(dict(dec=dec, d_syms=pkg.DeviceBuffer.from_numpy(syms), d_out=pkg.DeviceBuffer(nbits),
+        decs = []
+        for _ in range(max(1, a.split)):
+            dec = pkg.Viterbi224(a.delay + 2 * chunk, a.engine, a.k)
+            dec.set_option("chunk", chunk)
+            decs.append(dec)
+        segs.append(dict(dec=decs[0], decs=decs, d_syms=pkg.DeviceBuffer.from_numpy(syms), d_out=pkg.DeviceBuffer(nbits),
                          bits=bits, noise_mask=noise_mask))
     dec = segs[0]["dec"]
 
     slab = 8 * chunk                                     # bits handed over per call and segment
+    redone = [0]                                         # parts the split decode had to redo (seam check failed)
 
-    def step():
+    def step_single():
         # every segment has its own decoder and HIP streams.  With several segments per GPU the
         # enqueues are interleaved slab by slab, so that launches of different segments sit next to
         # each other in the device queues and overlap (one segment's loads/stores under another's
@@ -248,13 +258,40 @@ def main():
             for sg in segs:
                 sg["dec"].stream_decode_dev(sg["d_syms"], n, a.delay, sg["d_out"], sym_offset=2 * pos, out_offset=pos)
 
+    def step_split():
+        for sg in segs:
+            redone[0] += pkg.stream_decode_split(sg["decs"], sg["d_syms"], nbits, a.delay, sg["d_out"], a.split_warm)
+
     fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
-    harness.timed_steps(step, 0, a.warmup, fence)
-    dec.set_option("profile", 4)
-    dec.acs_stats(reset=True)
-    dt = harness.timed_steps(step, a.steps, 0, fence)
-    launches, ms, steps_timed = dec.acs_stats()
-    dec.set_option("profile", 0)
+    single = None
+    if a.split > 1:
+        # reference pass: ONE decoder per stream (1 warm-up + 1 timed step); its kernel timing feeds `roofline`, its
+        # output is what the split decode has to reproduce byte for byte
+        harness.timed_steps(step_single, 0, 1, fence)
+        dec.set_option("profile", 4)
+        dec.acs_stats(reset=True)
+        dt1 = harness.timed_steps(step_single, 1, 0, fence)
+        launches, ms, steps_timed = dec.acs_stats()
+        dec.set_option("profile", 0)
+        dt1 = harness.max_over_ranks(dist if world > 1 else None, torch, dt1, redev)
+        single_out = segs[0]["d_out"].to_numpy(np.uint8).copy()
+        harness.timed_steps(step_split, 0, a.warmup, fence)
+        redone[0] = 0
+        dec.set_option("profile", 4)
+        dec.acs_stats(reset=True)
+        dt = harness.timed_steps(step_split, a.steps, 0, fence)
+        l2, ms2, st2 = dec.acs_stats()
+        dec.set_option("profile", 0)
+        single = {"value": round(2 * nbits * nseg / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 3),
+                  "identical_output": bool(np.array_equal(single_out, segs[0]["d_out"].to_numpy(np.uint8))),
+                  "split_avg_launch_ms": round(ms2 / l2, 6) if l2 else None}
+    else:
+        harness.timed_steps(step_single, 0, a.warmup, fence)
+        dec.set_option("profile", 4)
+        dec.acs_stats(reset=True)
+        dt = harness.timed_steps(step_single, a.steps, 0, fence)
+        launches, ms, steps_timed = dec.acs_stats()
+        dec.set_option("profile", 0)
     dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, redev)
     d_out, bits, noise_mask = segs[0]["d_out"], segs[0]["bits"], segs[0]["noise_mask"]
 
@@ -295,7 +332,14 @@ def main():
                        "engine": {0: "simple", 1: "fused", 2: "lds8", 3: "lds15"}[eng],
                        "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8, 3: 15}[eng],
                        "chunk_bits": chunk,
-                       "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg},
+                       "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg,
+                       "decoders_per_stream": a.split,
+                       "split": None if a.split <= 1 else {
+                           "what": "each stream is cut into %d consecutive parts decoded at the same time by %d decoders; "
+                                   "part j > 0 warms up %d bits early and its path metrics are compared with the previous "
+                                   "decoder's at the seam (all 2^23 states equal => identical continuation, else the part is "
+                                   "decoded again): v224hip_stream_decode_split" % (a.split, a.split, a.split_warm),
+                           "parts_redone": redone[0], "single_decoder": single}},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tsrc,
@@ -305,6 +349,8 @@ def main():
                                  "VALU-issue bound, see DESIGN.md section 3",
                          "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_STEP * steps_per_launch),
                          "kernel": kern,
+                         "measured_on": "the single-decoder reference pass of this run (one k_acs_lds15 at a time on the GPU); in "
+                                        "the split pass two decoders' launches overlap" if a.split > 1 else "the timed steps",
                          "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "launches_timed": launches},
             "check": {"ber_clean": ber, "bits": int(clean.sum())},
@@ -314,7 +360,8 @@ def main():
             res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
     for sg in segs:
-        sg["dec"].close()
+        for d in sg["decs"]:
+            d.close()
     if world > 1:
         dist.destroy_process_group()
 

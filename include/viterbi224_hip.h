@@ -45,6 +45,18 @@ int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, ui
 int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbits, int delay, uint8_t *d_out);
 int v224hip_stream_chunk(void *p);                 /* bits per internal chunk (option "chunk") */
 
+/* ONE stream decoded by several decoders at the same time, with the result of a single decoder -- verified.
+ * The stream is cut into ndec consecutive parts (multiples of the stream chunk); decoder j > 0 starts `warm_bits`
+ * before its part from a fresh init(0).  1020 bits (one chunk) before the part begins, its path metrics minus their
+ * minimum are compared, for all 2^23 states, with those of decoder j-1 at the same trellis step.  If they are equal,
+ * every later decision of the two is equal (the recursion port.c:168-181 only ever compares metrics), so decoder j's
+ * output from its part on is what decoder j-1 would have gone on to produce.  If they are not, the rest of the stream
+ * is decoded again by decoder j-1 from where it stands; *nfallback = number of parts redone (0 in practice with a
+ * warm-up of a few thousand bits).  Device buffers; all decoders on one device, same chunk, len >= delay + 2*chunk.
+ * out[] is exactly what init(0) + v224hip_stream_decode_dev() of one decoder writes. */
+int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
+                                uint8_t *d_out, int warm_bits, int *nfallback);
+
 /* A batch of independent frames, each decoded as vtest224.c:116-118 / decode.c:220-222 do it:
  *   init_viterbi224(d, startstate); update_viterbi224_blk(d, syms + f*2*framebits, framebits);
  *   chainback_viterbi224(d, out + f*((framebits+7)/8), framebits, endstate);

@@ -30,7 +30,7 @@ V224_SYMBOLS = [
     "decodebit_viterbi224", "decodeword_viterbi224",
     "v224hip_device_count", "v224hip_set_device", "v224hip_create", "v224hip_last_error",
     "v224hip_update_dev", "v224hip_stream_decode", "v224hip_stream_decode_dev",
-    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
+    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
     "v224hip_export_row", "v224hip_export_metrics", "v224hip_dev_alloc", "v224hip_dev_free",
     "v224hip_h2d", "v224hip_d2h",
 ]
@@ -78,6 +78,8 @@ def v224_lib():
     L.v224hip_stream_decode.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p]
     L.v224hip_stream_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.v224hip_stream_chunk.argtypes = [C.c_void_p]
+    L.v224hip_stream_decode_split.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_int, C.POINTER(C.c_int)]
     L.v224hip_decode_frames.argtypes = [C.POINTER(C.c_void_p), C.c_int, u8p, C.c_int, C.c_int, C.c_int,
                                         C.c_uint, u8p]
     L.v224hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
@@ -251,6 +253,19 @@ DSP_SYMBOLS = [
     "pmd_get_spectrum",
 ]
 
+
+
+def stream_decode_split(decoders, d_syms, nbits, delay, d_out, warm_bits=14280, sym_offset=0, out_offset=0):
+    """v224hip_stream_decode_split: one stream over several decoders with a single decoder's result (verified at
+    the seams; see include/viterbi224_hip.h).  Device buffers.  Returns the number of parts that had to be redone."""
+    L = v224_lib()
+    hs = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+    nfb = C.c_int(0)
+    rc = L.v224hip_stream_decode_split(hs, len(decoders), d_syms.ptr + sym_offset, int(nbits), int(delay),
+                                       d_out.ptr + out_offset, int(warm_bits), C.byref(nfb))
+    if rc != 0:
+        raise RuntimeError("v224hip_stream_decode_split: " + L.v224hip_last_error().decode())
+    return nfb.value
 
 
 def decode_frames(decoders, syms, nframes, framebits, startstate=0, endstate=0):

@@ -880,6 +880,145 @@ fail:
   return -1;
 }
 
+// ---- one stream over several decoders, verified -------------------------------------------------------
+// dst[i] = m[i] - (minimum of m): what two decoders must agree on for their futures to be identical
+__global__ __launch_bounds__(256) void k_snapshot_rel(const uint16_t *__restrict__ m, const V224Dev *ds, unsigned pass,
+                                                      uint16_t *__restrict__ dst) {
+  const unsigned mn = input_min(ds, pass);
+  const unsigned t = blockIdx.x * 256 + threadIdx.x;           // 2^20 threads x 8 states
+  uint4 v = reinterpret_cast<const uint4 *>(m)[t];
+  const unsigned sub = (mn & 0xffffu) * 0x10001u;
+  v.x = as_u32(as_v2(v.x) - as_v2(sub)); v.y = as_u32(as_v2(v.y) - as_v2(sub));
+  v.z = as_u32(as_v2(v.z) - as_v2(sub)); v.w = as_u32(as_v2(v.w) - as_v2(sub));
+  reinterpret_cast<uint4 *>(dst)[t] = v;
+}
+__global__ __launch_bounds__(256) void k_count_diff(const uint4 *__restrict__ a, const uint4 *__restrict__ b, unsigned *count) {
+  const unsigned t = blockIdx.x * 256 + threadIdx.x;
+  const uint4 x = a[t], y = b[t];
+  const bool d = (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+  if (__syncthreads_or(d) && threadIdx.x == 0) atomicAdd(count, 1u);
+}
+
+struct SplitItem { long long bit0; long long nbits; uint8_t *out; int snap; };   // snap: 0 none, else seam index (+ = as A, - = as B)
+
+extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
+                                           uint8_t *d_out, int warm_bits, int *nfallback) {
+  uint16_t *snapA[8] = {nullptr}, *snapB[8] = {nullptr};
+  uint8_t *scratch[8] = {nullptr};
+  unsigned *d_cnt = nullptr, h_cnt[8] = {0};
+  hipEvent_t evA[8] = {nullptr}, evB[8] = {nullptr};
+  int rc = -1, fb = 0;
+  if (nfallback) *nfallback = 0;
+  if (!decoders || ndec < 1 || ndec > 8 || !d_syms || !d_out || nbits < 0 || delay <= 0) {
+    snprintf(g_err, sizeof g_err, "stream_decode_split: bad argument");
+    return -1;
+  }
+  V224 *v0 = (V224 *)decoders[0];
+  for (int j = 0; j < ndec; j++) {
+    V224 *v = (V224 *)decoders[j];
+    if (!v || v->dev != v0->dev || v->chunk != v0->chunk || v->len < delay + 2 * v->chunk) {
+      snprintf(g_err, sizeof g_err, "stream_decode_split: decoder %d is NULL, on another device, has another chunk size or a short ring", j);
+      return -1;
+    }
+  }
+  const long long chunk = v0->chunk, check = chunk;
+  long long warm = ((long long)warm_bits + chunk - 1) / chunk * chunk;
+  if (warm < 2 * chunk) warm = 2 * chunk;
+  // parts: equal finishing times => part 0 is `warm` longer than the others' own share
+  int P = ndec;
+  while (P > 1 && ((long long)nbits + (P - 1) * warm) / P / chunk * chunk < warm + chunk) P--;     // too short to split that far
+  long long start[9];
+  {
+    const long long per = P > 1 ? ((long long)nbits + (P - 1) * warm) / P / chunk * chunk : nbits;   // bits each decoder processes
+    start[0] = 0;
+    for (int j = 1; j < P; j++) start[j] = per + (long long)(j - 1) * (per - warm);
+    start[P] = nbits;
+  }
+  HIPCHK(hipSetDevice(v0->dev));
+  if (P > 1) {
+    HIPCHK(hipMalloc(&d_cnt, 8 * sizeof(unsigned)));
+    HIPCHK(hipMemset(d_cnt, 0, 8 * sizeof(unsigned)));
+  }
+  for (int j = 1; j < P; j++) {
+    HIPCHK(hipMalloc(&snapA[j], sizeof(uint16_t) * V224_NSTATES));
+    HIPCHK(hipMalloc(&snapB[j], sizeof(uint16_t) * V224_NSTATES));
+    HIPCHK(hipMalloc(&scratch[j], (size_t)warm));
+    HIPCHK(hipEventCreateWithFlags(&evA[j], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&evB[j], hipEventDisableTiming));
+  }
+  {
+    // work lists: decoder j warms up from start[j] - warm, snapshots at the checkpoint start[j] - check (as B of seam j),
+    // decodes its part, and snapshots at start[j+1] - check on the way (as A of seam j+1)
+    std::vector<SplitItem> work[8];
+    for (int j = 0; j < P; j++) {
+      if (j > 0) {
+        work[j].push_back({start[j] - warm, warm - check, scratch[j], -j});
+        work[j].push_back({start[j] - check, check, scratch[j] + (warm - check), 0});
+      }
+      if (j < P - 1) {
+        work[j].push_back({start[j], start[j + 1] - check - start[j], d_out + start[j], j + 1});
+        work[j].push_back({start[j + 1] - check, check, d_out + start[j + 1] - check, 0});
+      } else work[j].push_back({start[j], start[j + 1] - start[j], d_out + start[j], 0});
+    }
+    size_t it[8] = {0}; long long done[8] = {0};
+    const long long slab = 8 * chunk;
+    for (int j = 0; j < P; j++) if (init_viterbi224(decoders[j], 0) != 0) goto fail;
+    for (bool any = true; any;) {                       // slab by slab, round robin, so that the decoders' launches interleave
+      any = false;
+      for (int j = 0; j < P; j++) {
+        if (it[j] >= work[j].size()) continue;
+        any = true;
+        V224 *v = (V224 *)decoders[j];
+        SplitItem &w = work[j][it[j]];
+        const long long n = w.nbits - done[j] < slab ? w.nbits - done[j] : slab;
+        if (n > 0 && v224hip_stream_decode_dev(v, d_syms + 2 * (w.bit0 + done[j]), (int)n, delay, w.out + done[j]) != 0) goto fail;
+        done[j] += n;
+        if (done[j] >= w.nbits) {
+          if (w.snap != 0) {
+            const int seam = w.snap > 0 ? w.snap : -w.snap;
+            ensure_layout(v, 1);                       // both sides of a seam are compared in the same (tile) order
+            ensure_min_valid(v);
+            k_snapshot_rel<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, w.snap > 0 ? snapA[seam] : snapB[seam]);
+            HIPCHK(hipEventRecord(w.snap > 0 ? evA[seam] : evB[seam], v->st));
+          }
+          it[j]++; done[j] = 0;
+        }
+      }
+    }
+    for (int j = 1; j < P; j++) {                       // all snapshots are enqueued: compare
+      HIPCHK(hipStreamWaitEvent(v0->st, evA[j], 0));
+      HIPCHK(hipStreamWaitEvent(v0->st, evB[j], 0));
+      k_count_diff<<<V224_NSTATES / 8 / 256, 256, 0, v0->st>>>(reinterpret_cast<const uint4 *>(snapA[j]),
+                                                                reinterpret_cast<const uint4 *>(snapB[j]), d_cnt + j);
+    }
+    HIPCHK(hipGetLastError());
+    for (int j = 0; j < P; j++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[j])->st));
+    if (P > 1) HIPCHK(hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost));
+    if (P > 1 && getenv("V224HIP_SPLIT_FORCE_FALLBACK")) h_cnt[P - 1] = 1;         // test hook: exercise the redo path
+    for (int j = 1; j < P; j++) {
+      if (h_cnt[j] == 0) continue;
+      // the warm-up of part j had not forgotten its start: everything from start[j] on is decoded again by the
+      // decoder of part j-1, which stands exactly there with the true path metrics
+      fb = P - j;
+      if (v224hip_stream_decode_dev(decoders[j - 1], d_syms + 2 * start[j], (int)(nbits - start[j]), delay, d_out + start[j]) != 0) goto fail;
+      HIPCHK(hipStreamSynchronize(((V224 *)decoders[j - 1])->st));
+      break;
+    }
+  }
+  if (nfallback) *nfallback = fb;
+  rc = 0;
+fail:
+  for (int j = 0; j < 8; j++) {
+    if (snapA[j]) (void)hipFree(snapA[j]);
+    if (snapB[j]) (void)hipFree(snapB[j]);
+    if (scratch[j]) (void)hipFree(scratch[j]);
+    if (evA[j]) (void)hipEventDestroy(evA[j]);
+    if (evB[j]) (void)hipEventDestroy(evB[j]);
+  }
+  if (d_cnt) (void)hipFree(d_cnt);
+  return rc;
+}
+
 extern "C" int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, uint8_t *out) {
   V224 *v = (V224 *)p;
   if (!v) return -1;

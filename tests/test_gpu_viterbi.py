@@ -358,3 +358,55 @@ def test_lds15_ragged_updates_small_ring(pkg, length):
         assert int(m[st]) == o.metric_rel(st)
     d.close()
     o.close()
+
+
+def test_split_stream_is_verified_and_exact(pkg, monkeypatch):
+    """v224hip_stream_decode_split: one stream over 2 and 3 decoders == the same stream through one decoder, bit for
+    bit (0xff start-up marks included).  On a coded stream the seams verify (no part redone); whatever the
+    comparison at a seam says -- pure noise with a short warm-up, or a forced mismatch -- the output is exact."""
+    delay = 200
+    for seed, nbits, noise_pct, warm, ndec, force in ((9400, 61200, 5, 14280, 2, False), (9401, 91800, 5, 8160, 3, False),
+                                                      (9402, 30600, 100, 2040, 2, False), (9403, 40800, 5, 14280, 2, True)):
+        syms, _ = orc.gen_coded_stream(seed, nbits, 2.5, 24.0, noise_pct)
+        d = pkg.Viterbi224(delay + 2 * 1020)
+        d.init(0)
+        want = d.stream_decode(syms, delay)
+        d.close()
+        decs = [pkg.Viterbi224(delay + 2 * 1020) for _ in range(ndec)]
+        dsy = pkg.DeviceBuffer.from_numpy(syms)
+        dout = pkg.DeviceBuffer(nbits)
+        if force:
+            monkeypatch.setenv("V224HIP_SPLIT_FORCE_FALLBACK", "1")
+        nfb = pkg.stream_decode_split(decs, dsy, nbits, delay, dout, warm_bits=warm)
+        monkeypatch.delenv("V224HIP_SPLIT_FORCE_FALLBACK", raising=False)
+        got = dout.to_numpy(np.uint8)
+        assert np.array_equal(got, want), "seed %d" % seed
+        if force:
+            assert nfb == 1
+        elif noise_pct < 100:
+            assert nfb == 0, "seed %d: %d parts redone" % (seed, nfb)
+        for x in decs:
+            x.close()
+
+
+@pytest.mark.slow
+def test_split_equals_single_at_full_bench_size(pkg):
+    """BASELINE configs[1] at full size (10^7 symbols, bench.py's own input): two decoders on consecutive parts,
+    verified at the seam, give byte for byte what one decoder gives."""
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+    nbits, delay = 5_000_000, 200
+    syms, _, _ = synth.coded_stream(1000, nbits, 3.0, 24.0, 1.0)
+    dsy = pkg.DeviceBuffer.from_numpy(syms)
+    decs = [pkg.Viterbi224(delay + 2 * 1020) for _ in range(2)]
+    d1 = pkg.DeviceBuffer(nbits)
+    decs[0].init(0)
+    for pos in range(0, nbits, 8160):
+        decs[0].stream_decode_dev(dsy, min(8160, nbits - pos), delay, d1, sym_offset=2 * pos, out_offset=pos)
+    decs[0].sync()
+    one = d1.to_numpy(np.uint8).copy()
+    d2 = pkg.DeviceBuffer(nbits)
+    assert pkg.stream_decode_split(decs, dsy, nbits, delay, d2) == 0
+    assert np.array_equal(d2.to_numpy(np.uint8), one)
+    for x in decs:
+        x.close()
