@@ -29,6 +29,9 @@ int isee3_chain_run_mem(const isee3_chain_opts *o, const int16_t *iq, size_t nsa
 /* same on file descriptors: reads int16 IQ from fd_in until EOF, writes bits to fd_out */
 int isee3_chain_run_fd(const isee3_chain_opts *o, int fd_in, int fd_out);
 const char *isee3_chain_last_error(void);
+/* The library keeps the Viterbi decoder objects of finished calls (2.2 GiB of HBM each, at most four) for the next
+ * call; this frees them. */
+void isee3_chain_release(void);
 
 #ifdef __cplusplus
 }

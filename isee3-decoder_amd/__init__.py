@@ -437,7 +437,7 @@ def cli_path(name):
 # ------------------------------------------------------------------------------------------------
 # libisee3chain.so : pmdemod | symdemod | vdecode on memory buffers (include/isee3_chain.h)
 # ------------------------------------------------------------------------------------------------
-CHAIN_SYMBOLS = ["isee3_chain_default_opts", "isee3_chain_run_mem", "isee3_chain_run_fd", "isee3_chain_last_error"]
+CHAIN_SYMBOLS = ["isee3_chain_default_opts", "isee3_chain_run_mem", "isee3_chain_run_fd", "isee3_chain_last_error", "isee3_chain_release"]
 
 
 class ChainOpts(C.Structure):

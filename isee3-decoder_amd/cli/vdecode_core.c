@@ -38,6 +38,88 @@ int vdecode_parse_args(vdecode_opts *o, int argc, char **argv) {
 
 typedef struct { size_t at_pair; } flip_event;
 
+/* pass 1 state (depends on the input only) and pass 2 state (consumes decoder output) */
+typedef struct {
+  unsigned char ring[RING], pair[2];
+  int pos, sync_count, peak_in, peak_out;
+} p1_state;
+typedef struct {
+  int startup, flips;
+  unsigned long long reenc, symerrs, bits, symerrs_total, bits_out;
+} p2_state;
+
+/* pairing + phase tracking over one input block (vdecode.c:104-141): appends pairs to syms/hard from index np on,
+ * flip events to fl; returns the new pair count */
+static size_t pass1(const vdecode_opts *o, p1_state *st, const unsigned char *in, size_t got, int delay,
+                    unsigned char *syms, unsigned char *hard, size_t np, flip_event *fl, size_t *nfl) {
+  unsigned char *ring = st->ring;
+  int pos = st->pos;
+  for (size_t n = 0; n < got; n++) {
+    unsigned char c = in[n];
+    ring[pos] = c; st->pair[pos % 2] = c;
+    if (!o->dontflip) {
+      int sum = 0;
+      for (int k = 0; k < 34; k++) sum += sync_sign[k] * ((int)ring[(RING + pos + k - 33) % RING] - 128);
+      if ((pos % 2) == 0) { if (sum > st->peak_out) st->peak_out = sum; }
+      else {
+        if (sum > st->peak_in) st->peak_in = sum;
+        if (++st->sync_count >= ISEE3_FRAMESYMBOLS) {
+          st->sync_count = 0;
+          if (st->peak_out > st->peak_in) {           /* other phase had the stronger sync: flip */
+            fl[(*nfl)++].at_pair = np;
+            if ((pos % 2) == 0) pos++; else pos--;
+          }
+          st->peak_in = st->peak_out = -1000000;
+        }
+      }
+    }
+    if ((pos % 2) == 1) {
+      syms[2 * np] = st->pair[0]; syms[2 * np + 1] = st->pair[1];
+      /* hard slices of the symbols the re-encoder will be compared with (vdecode.c:174-177) */
+      /* same index expressions as the reference, made safe for delays beyond ~2000 where
+         the reference's own expression goes negative */
+      int back = 2 * (delay + ISEE3_K - 2);
+      unsigned h1 = ring[(((pos - back - 1) % RING) + RING) % RING] > 128;
+      unsigned h2 = ring[(((pos - back) % RING) + RING) % RING] > 128;
+      hard[np] = (unsigned char)(h1 | (h2 << 1));
+      np++;
+    }
+    pos = (pos + 1) % RING;
+  }
+  st->pos = pos;
+  return np;
+}
+
+/* start-up suppression, output, re-encode statistics, status lines for pairs [j0, j1) (vdecode.c:151-184) */
+static void pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec, const unsigned char *hard,
+                  size_t j0, size_t j1, const flip_event *fl, size_t nfl, size_t *f, char *obuf, FILE *out, FILE *err) {
+  size_t no = 0;
+  for (size_t j = j0; j < j1; j++) {
+    while (*f < nfl && fl[*f].at_pair == j) {
+      st->flips++; (*f)++;
+      if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0);
+    }
+    if (st->startup == 0) {
+      unsigned bit = dec[j] & 1u;
+      obuf[no++] = bit ? '1' : '0';
+      st->reenc = (st->reenc << 1) | bit;
+    } else st->startup--;
+    int s1 = ISEE3_G1FLIP ^ isee3_parity(st->reenc & ISEE3_POLY1);
+    int s2 = ISEE3_G2FLIP ^ isee3_parity(st->reenc & ISEE3_POLY2);
+    if (st->startup == 0) {
+      unsigned add = (unsigned)(s1 ^ (hard[j] & 1)) + (unsigned)(s2 ^ ((hard[j] >> 1) & 1));
+      st->symerrs += add; st->symerrs_total += add;
+    }
+    if (!o->quiet && o->status_interval != 0 && (++st->bits % (unsigned long long)o->status_interval) == 0) {
+      fprintf(err, "%s: bits %'llu; symerrs %'llu/%'d %'.3lg%%\n", o->argv0, st->bits, st->symerrs,
+              2 * o->status_interval, 100. * st->symerrs / (2. * o->status_interval));
+      st->symerrs = 0;
+    }
+  }
+  if (no) { fwrite(obuf, 1, no, out); fflush(out); }
+  st->bits_out += no;
+}
+
 int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE *out, FILE *err,
                 vdecode_result *res) {
   enum { INBLK = 1 << 16 };
@@ -48,93 +130,67 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
   } else if (delay > 1024) {
     fprintf(err, "%s: Warning; excessive decode delay; 1MB/bit needed\n", o->argv0);
   }
-  int startup = delay;
-  unsigned char ring[RING], pair[2] = { 0, 0 };
-  for (int i = 0; i < RING; i += 2) { ring[i] = ISEE3_G1FLIP ? 255 : 0; ring[i + 1] = ISEE3_G2FLIP ? 255 : 0; }
-  int pos = o->start_phase ? 1 : 0;           /* low bit = decoder symbol phase */
-  int sync_count = 0, peak_in = -1000000, peak_out = -1000000;
-  unsigned long long reenc = 0, symerrs = 0, bits = 0, symerrs_total = 0, bits_out = 0;
-  int flips = 0, rc = -1;
-
-  unsigned char *inbuf = malloc(INBLK), *syms = malloc(INBLK), *hard = malloc(INBLK / 2 + 1);
-  unsigned char *dec = malloc(INBLK / 2 + 1);
-  char *obuf = malloc(INBLK / 2 + 1);
-  flip_event *fl = malloc(sizeof(flip_event) * (INBLK / ISEE3_FRAMESYMBOLS + 2));
+  p1_state s1; p2_state s2;
+  memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2);
+  for (int i = 0; i < RING; i += 2) { s1.ring[i] = ISEE3_G1FLIP ? 255 : 0; s1.ring[i + 1] = ISEE3_G2FLIP ? 255 : 0; }
+  s1.pos = o->start_phase ? 1 : 0;            /* low bit = decoder symbol phase */
+  s1.peak_in = s1.peak_out = -1000000;
+  s2.startup = delay;
+  int rc = -1;
+  /* whole-input mode: the engine can decode one long stream faster than many short blocks (two decoders on
+   * consecutive parts), so when the caller says the input is finite and latency does not matter, pass 1 runs over ALL
+   * of it first.  Same pairs, same decoder output, same pass 2: stdout is byte-identical either way. */
+  const int whole = o->whole_input && e->stream_decode_whole != NULL;
+  size_t cap = INBLK / 2 + 1, flcap = INBLK / ISEE3_FRAMESYMBOLS + 2;
+  unsigned char *inbuf = malloc(INBLK), *syms = malloc(2 * cap), *hard = malloc(cap), *dec = malloc(cap);
+  char *obuf = malloc(whole ? 1 : cap);
+  flip_event *fl = malloc(sizeof(flip_event) * flcap);
   void *vd = e->create(delay + 1 + e->ring_extra);
   if (!inbuf || !syms || !hard || !dec || !obuf || !fl || !vd) goto done;
   e->init(vd, 0);
 
-  for (;;) {
-    ssize_t got = read(fd_in, inbuf, INBLK);
-    if (got <= 0) break;
-    /* pass 1: pairing + phase tracking (depends on the input only) */
-    size_t np = 0, nfl = 0;
-    for (ssize_t n = 0; n < got; n++) {
-      unsigned char c = inbuf[n];
-      ring[pos] = c; pair[pos % 2] = c;
-      if (!o->dontflip) {
-        int sum = 0;
-        for (int k = 0; k < 34; k++) sum += sync_sign[k] * ((int)ring[(RING + pos + k - 33) % RING] - 128);
-        if ((pos % 2) == 0) { if (sum > peak_out) peak_out = sum; }
-        else {
-          if (sum > peak_in) peak_in = sum;
-          if (++sync_count >= ISEE3_FRAMESYMBOLS) {
-            sync_count = 0;
-            if (peak_out > peak_in) {           /* other phase had the stronger sync: flip */
-              fl[nfl++].at_pair = np;
-              if ((pos % 2) == 0) pos++; else pos--;
-            }
-            peak_in = peak_out = -1000000;
-          }
-        }
-      }
-      if ((pos % 2) == 1) {
-        syms[2 * np] = pair[0]; syms[2 * np + 1] = pair[1];
-        /* hard slices of the symbols the re-encoder will be compared with (vdecode.c:174-177) */
-        /* same index expressions as the reference, made safe for delays beyond ~2000 where
-           the reference's own expression goes negative */
-        int back = 2 * (delay + ISEE3_K - 2);
-        unsigned h1 = ring[(((pos - back - 1) % RING) + RING) % RING] > 128;
-        unsigned h2 = ring[(((pos - back) % RING) + RING) % RING] > 128;
-        hard[np] = (unsigned char)(h1 | (h2 << 1));
-        np++;
-      }
-      pos = (pos + 1) % RING;
+  if (!whole) {
+    for (;;) {
+      ssize_t got = read(fd_in, inbuf, INBLK);
+      if (got <= 0) break;
+      size_t nfl = 0, f = 0;
+      size_t np = pass1(o, &s1, inbuf, (size_t)got, delay, syms, hard, 0, fl, &nfl);
+      /* the engine: np trellis steps, one traceback each */
+      if (np && e->stream_decode(vd, syms, (int)np, delay, dec) != 0) goto done;
+      pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err);
+      while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
     }
-    /* the engine: np trellis steps, one traceback each */
-    if (np && e->stream_decode(vd, syms, (int)np, delay, dec) != 0) goto done;
-    /* pass 2: start-up suppression, output, re-encode statistics, status lines */
-    size_t no = 0, f = 0;
-    for (size_t j = 0; j < np; j++) {
-      while (f < nfl && fl[f].at_pair == j) {
-        flips++; f++;
-        if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0);
+  } else {
+    size_t np = 0, nfl = 0, f = 0;
+    for (;;) {
+      ssize_t got = read(fd_in, inbuf, INBLK);
+      if (got <= 0) break;
+      if (np + (size_t)got / 2 + 2 > cap) {
+        cap = 2 * cap + (size_t)got;
+        unsigned char *a = realloc(syms, 2 * cap), *b = realloc(hard, cap);
+        if (a) syms = a;
+        if (b) hard = b;
+        if (!a || !b) goto done;
       }
-      if (startup == 0) {
-        unsigned bit = dec[j] & 1u;
-        obuf[no++] = bit ? '1' : '0';
-        reenc = (reenc << 1) | bit;
-      } else startup--;
-      int s1 = ISEE3_G1FLIP ^ isee3_parity(reenc & ISEE3_POLY1);
-      int s2 = ISEE3_G2FLIP ^ isee3_parity(reenc & ISEE3_POLY2);
-      if (startup == 0) {
-        unsigned add = (unsigned)(s1 ^ (hard[j] & 1)) + (unsigned)(s2 ^ ((hard[j] >> 1) & 1));
-        symerrs += add; symerrs_total += add;
+      if (nfl + (size_t)got / ISEE3_FRAMESYMBOLS + 2 > flcap) {
+        flcap = 2 * flcap + (size_t)got / ISEE3_FRAMESYMBOLS + 2;
+        flip_event *c = realloc(fl, sizeof(flip_event) * flcap);
+        if (!c) goto done;
+        fl = c;
       }
-      if (!o->quiet && o->status_interval != 0 && (++bits % (unsigned long long)o->status_interval) == 0) {
-        fprintf(err, "%s: bits %'llu; symerrs %'llu/%'d %'.3lg%%\n", o->argv0, bits, symerrs,
-                2 * o->status_interval, 100. * symerrs / (2. * o->status_interval));
-        symerrs = 0;
-      }
+      np = pass1(o, &s1, inbuf, (size_t)got, delay, syms, hard, np, fl, &nfl);
     }
-    while (f < nfl) { flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
-    if (no) { fwrite(obuf, 1, no, out); fflush(out); }
-    bits_out += no;
+    free(dec); dec = malloc(np + 1);
+    free(obuf); obuf = malloc(np + 1);
+    if (!dec || !obuf) goto done;
+    if (np && e->stream_decode_whole(vd, syms, (long long)np, delay, dec) != 0) goto done;
+    pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err);
+    while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
   }
   rc = 0;
 done:
   if (vd) e->destroy(vd);
   free(inbuf); free(syms); free(hard); free(dec); free(obuf); free(fl);
-  if (res) { res->bits_out = bits_out; res->symerrs_total = symerrs_total; res->flips = flips; }
+  if (res) { res->bits_out = s2.bits_out; res->symerrs_total = s2.symerrs_total; res->flips = s2.flips; }
   return rc;
 }

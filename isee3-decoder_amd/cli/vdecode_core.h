@@ -16,6 +16,7 @@ typedef struct {
   int status_interval;   /* -i, default 1024 */
   int quiet;             /* -q */
   int dontflip;          /* -F */
+  int whole_input;       /* not a reference option: read ALL input before decoding (finite input, latency irrelevant) */
   const char *argv0;
 } vdecode_opts;
 
@@ -27,6 +28,8 @@ typedef struct {
   int   (*stream_decode)(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out);
   void  (*destroy)(void *h);
   int   ring_extra;      /* rows the engine needs beyond decode_delay */
+  /* optional (may be NULL): the same contract as stream_decode for one long stream right after init */
+  int   (*stream_decode_whole)(void *h, const unsigned char *syms, long long nbits, int delay, unsigned char *out);
 } vdecode_engine;
 
 typedef struct {

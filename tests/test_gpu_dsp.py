@@ -279,3 +279,19 @@ def test_segmented_decode_matches_single_pass(pkg):
     assert n > 18000 and bits[:n - 64] == single[:n - 64]
     # planning: block-aligned, covering, warm-up clipped at the start
     assert seg.plan_segments(24, 4, 3) == [(0, 0, 6), (3, 6, 12), (9, 12, 18), (15, 18, 24)]
+
+
+def test_vdecode_cli_file_input_uses_both_decoders_same_output(pkg, tmp_path):
+    """`vdecode < file`: all input is known up front, so the stage decodes the stream in two halves on two decoders
+    (verified split); `cat file | vdecode` decodes block by block on one.  Same bytes -- through a forced phase flip."""
+    nbits = 100_000
+    syms, _ = orc.gen_coded_stream(9500, nbits, 3.0, 24.0, 2)
+    syms = np.concatenate([syms[:60001], syms[60002:]])            # a lost symbol: the phase tracker has to flip
+    f = tmp_path / "syms.u8"
+    f.write_bytes(syms.tobytes())
+    exe = pkg.cli_path("vdecode")
+    piped = subprocess.run([exe, "-q"], input=syms.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    with open(f, "rb") as fh:
+        filed = subprocess.run([exe, "-q"], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert piped.returncode == 0 and filed.returncode == 0, filed.stderr
+    assert len(piped.stdout) > 99_000 and piped.stdout == filed.stdout

@@ -34,11 +34,15 @@ def harness():
     return exe
 
 
+@pytest.mark.parametrize("whole", ["0", "1"], ids=["blockwise", "whole_input"])
 @pytest.mark.parametrize("name", _names())
-def test_host_logic_with_oracle_engine(harness, name):
+def test_host_logic_with_oracle_engine(harness, name, whole):
+    """block by block as the input arrives (the reference's way), or pass 1 over ALL input first and one engine call
+    (whole-input mode, what the chain and `vdecode < file` use): the same stdout"""
     z = np.load(G)
     p = subprocess.run([harness, "-q"] + _args(z, name), input=z[name + "/syms"].tobytes(),
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600,
+                       env=dict(os.environ, VDECODE_WHOLE=whole))
     assert p.stdout == z[name + "/stdout"].tobytes()
     if name == "flip":
         assert b"flips=1" in p.stderr
