@@ -12,7 +12,7 @@
 //             are only ever compared pairwise and their spread is < 12 731 + 510, so a common
 //             offset can be subtracted at will (struct V224Dev::off keeps the running total).
 //   decisions ring of `len` rows x 1 MiB; rowmeta[row] says in which bit order the row was
-//             written (port order by the simple engine, permuted by the fused engine).
+//             written (port order by the simple engine, permuted by the multi-step engines).
 //   V224Dev   per-workgroup minima + running offset, updated by the kernels themselves.
 //
 // Engines:
@@ -23,6 +23,13 @@
 //           in packed-u16 VGPRs, so metric traffic drops to 32 MiB / K per step.
 //   LDS     see v224_lds.hip.inc: 8 steps per launch, 32 KiB tiles staged in LDS, two register
 //           levels of 4 steps each, lane-contiguous stores.
+//   LDS15   see v224_lds15.hip.inc (default): 15 steps per launch, one 64 KiB tile per workgroup, four
+//           register levels; metrics kept in a tile-major order between launches (layout = 1), converted
+//           back for anything that needs the natural order.
+//
+// Beyond the reference's nine functions (include/viterbi224_hip.h): block streaming decode with the tracebacks
+// on a second stream, a batch of independent frames over several decoders, and ONE stream decoded by several
+// decoders at once whose seams are verified (equal path metrics up to a constant => identical continuation).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
