@@ -22,38 +22,84 @@
 #include "../../include/viterbi224_hip.h"
 #include "../../include/isee3_chain.h"
 
-/* ---- engines (same bindings as the stand-alone mains) ---- */
-static void *pm_create(int n) { return pmd_create(n); }
-static int pm_dechirp(void *h, const double *t) { return pmd_set_dechirp(h, t); }
-static int pm_load(void *h, const int16_t *iq, int flip) { return pmd_load(h, iq, 0, flip); }
+/* ---- engines (same bindings as the stand-alone mains), except that the handles of a finished call are kept for the
+ * next one: creating and destroying the pmdemod / symdemod / Viterbi objects costs 3.5 + 3.5 + 8.5 ms of a 52 ms
+ * capture.  isee3_chain_release() frees what is kept. ---- */
+#define H_POOL 4
+typedef struct { void *h; int n; } pooled;
+static pthread_mutex_t g_hpool_mu = PTHREAD_MUTEX_INITIALIZER;
+static pooled g_pm_pool[H_POOL], g_sy_pool[H_POOL];
+static void *pool_take(pooled *pool, int n) {
+  void *h = NULL;
+  pthread_mutex_lock(&g_hpool_mu);
+  for (int i = 0; i < H_POOL; i++) if (pool[i].h && pool[i].n == n) { h = pool[i].h; pool[i].h = NULL; break; }
+  pthread_mutex_unlock(&g_hpool_mu);
+  return h;
+}
+static int pool_give(pooled *pool, void *h, int n) {
+  int kept = 0;
+  pthread_mutex_lock(&g_hpool_mu);
+  for (int i = 0; i < H_POOL; i++) if (!pool[i].h) { pool[i].h = h; pool[i].n = n; kept = 1; break; }
+  pthread_mutex_unlock(&g_hpool_mu);
+  return kept;
+}
+typedef struct { void *h; int n; } dsp_ctx;       /* remembers the size the handle was made for */
+static void *pm_create(int n) {
+  dsp_ctx *c = malloc(sizeof *c);
+  if (!c) return NULL;
+  c->n = n; c->h = pool_take(g_pm_pool, n);
+  if (c->h) pmd_set_dechirp(c->h, NULL);            /* a kept handle may carry the last call's de-chirp table */
+  else c->h = pmd_create(n);
+  if (!c->h) { free(c); return NULL; }
+  return c;
+}
+#define PMH(x) (((dsp_ctx *)(x))->h)
+static int pm_dechirp(void *h, const double *t) { return pmd_set_dechirp(PMH(h), t); }
+static int pm_load(void *h, const int16_t *iq, int flip) { return pmd_load(PMH(h), iq, 0, flip); }
 static int pm_peak(void *h, int a, int b, pmdemod_peak *o) {
   pmd_peak p;
-  if (pmd_fft_peak(h, a, b, &p) != 0) return -1;
+  if (pmd_fft_peak(PMH(h), a, b, &p) != 0) return -1;
   o->peak = p.peak; o->maxenergy = p.maxenergy; o->peak_re = p.peak_re; o->peak_im = p.peak_im;
   o->next_re = p.next_re; o->next_im = p.next_im; o->prev_re = p.prev_re; o->prev_im = p.prev_im;
   return 0;
 }
 static int pm_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) {
   pmd_mix m;
-  if (pmd_mix_quantise(h, cstep, &m, out16, NULL, 0) != 0) return -1;
+  if (pmd_mix_quantise(PMH(h), cstep, &m, out16, NULL, 0) != 0) return -1;
   r->dc_re = m.dc_re; r->dc_im = m.dc_im; r->amplitude = m.amplitude; r->diffsumsq = m.diffsumsq;
   return 0;
 }
-static void pm_destroy(void *h) { pmd_destroy(h); }
+static void pm_destroy(void *p) {
+  dsp_ctx *c = p;
+  if (!c) return;
+  if (!pool_give(g_pm_pool, c->h, c->n)) pmd_destroy(c->h);
+  free(c);
+}
 
-static void *sy_create(int n) { return symd_create(n); }
-static int sy_load(void *h, const int16_t *s, int n) { return symd_load(h, s, n, 0); }
-static int sy_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) { return symd_timesearch(h, lo, sw, sc, ns, noff, en); }
-static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o, double *es) { return symd_demod(h, e, sc, ns, g, o, 0, es); }
-static void sy_destroy(void *h) { symd_destroy(h); }
+static void *sy_create(int n) {
+  dsp_ctx *c = malloc(sizeof *c);
+  if (!c) return NULL;
+  c->n = n; c->h = pool_take(g_sy_pool, n);
+  if (!c->h) c->h = symd_create(n);
+  if (!c->h) { free(c); return NULL; }
+  return c;
+}
+static int sy_load(void *h, const int16_t *s, int n) { return symd_load(PMH(h), s, n, 0); }
+static int sy_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) { return symd_timesearch(PMH(h), lo, sw, sc, ns, noff, en); }
+static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o, double *es) { return symd_demod(PMH(h), e, sc, ns, g, o, 0, es); }
+static void sy_destroy(void *p) {
+  dsp_ctx *c = p;
+  if (!c) return;
+  if (!pool_give(g_sy_pool, c->h, c->n)) symd_destroy(c->h);
+  free(c);
+}
 
 static int g_chunk = 1020;
 /* vdecode engine: one decoder for block-wise streaming; for one long stream (whole-input mode) a second decoder joins
  * and the stream is decoded in two halves at once, verified at the seam (v224hip_stream_decode_split) */
 typedef struct { void *d[2]; int len; } vd_ctx;
-/* Creating and deleting a decoder (2.2 GiB decision ring, placement probe) costs ~8.5 ms, 15 % of a 60 s / 250 kS/s
- * capture: decoders are kept between calls (a few, so that concurrent chains each find one); isee3_chain_release()
- * gives them back. */
+/* Viterbi decoders (2.2 GiB decision ring, placement probe) are kept between calls too: a few, so that concurrent
+ * chains each find one. */
 #define VD_POOL 4
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static vd_ctx *g_pool[VD_POOL];
@@ -74,6 +120,12 @@ void isee3_chain_release(void) {
   pthread_mutex_lock(&g_pool_mu);
   for (int i = 0; i < VD_POOL; i++) { vd_free(g_pool[i]); g_pool[i] = NULL; }
   pthread_mutex_unlock(&g_pool_mu);
+  pthread_mutex_lock(&g_hpool_mu);
+  for (int i = 0; i < H_POOL; i++) {
+    if (g_pm_pool[i].h) { pmd_destroy(g_pm_pool[i].h); g_pm_pool[i].h = NULL; }
+    if (g_sy_pool[i].h) { symd_destroy(g_sy_pool[i].h); g_sy_pool[i].h = NULL; }
+  }
+  pthread_mutex_unlock(&g_hpool_mu);
 }
 static void *vd_create(int len) {
   vd_ctx *c = NULL;
