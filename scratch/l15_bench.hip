@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
   hipMemcpy(syms, h.data(), h.size(), hipMemcpyHostToDevice);
   printf("m0 %p m1 %p rows %p rowmeta %p syms %p ds %p\n", (void *)m0, (void *)m1, (void *)rows, (void *)rowmeta, (void *)syms, (void *)ds);
   for (int rep = 0; rep < 1; rep++) {
-#define L(ABL, ALT, what) printf("LDS15 ALIAS=%d MSTORE=%d ABL=%2d alt=%d %-34s: %7.2f us/launch\n", L15_ALIAS, L15_MSTORE, ABL, ALT, what, run15<ABL, ALT>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
+#define L(ABL, ALT, what) printf("LDS15 DIRECTOUT=%d L0DIRECT=%d ABL=%2d alt=%d %-34s: %7.2f us/launch\n", L15_DIRECTOUT, L15_L0DIRECT, ABL, ALT, what, run15<ABL, ALT>(nlaunch, m0, m1, rows, nrows, syms, ds, rowmeta, st));
     L(0, false, "full, min in and out")
     L(0, true, "full, alternating min (library)")
     L(1, true, "no arithmetic (memory + LDS)")

@@ -45,9 +45,10 @@ def slot_of(level, th, a, h):
         return ((th >> 6) << 11) | (a << 7) | ((th & 63) << 1) | h
     if level == 2:      # reg <-> slot 6..3, th[9:2] <-> slot 14..7, th[1:0] <-> slot 2..1
         return ((th >> 2) << 7) | (a << 3) | ((th & 3) << 1) | h
-    # level 3: reg a = b9:b2:b1:b0, pack = slot 8; th[3:0]=slot 6..3, th[4]=slot 10, th[5]=slot 7, th[9:6]=slot 14..11
+    # level 3 (direct output rows): reg a = b9:b2:b1:b0, pack = slot 8; th[9:6]=slot 6..3 (wave), th[5:2]=slot 14..11,
+    # th[1]=slot 10, th[0]=slot 7
     b9, low3 = a >> 3, a & 7
-    return (((th >> 6) & 15) << 11) | (((th >> 4) & 1) << 10) | (b9 << 9) | (h << 8) | (((th >> 5) & 1) << 7) | ((th & 15) << 3) | low3
+    return (((th >> 2) & 15) << 11) | (((th >> 1) & 1) << 10) | (b9 << 9) | (h << 8) | ((th & 1) << 7) | (((th >> 6) & 15) << 3) | low3
 
 
 def reg_pair_bit(level, t):
@@ -63,7 +64,7 @@ def locate(level, q):
         return ((q >> 11) << 6) | ((q >> 1) & 63), (q >> 7) & 15, q & 1
     if level == 2:
         return ((q >> 7) << 2) | ((q >> 1) & 3), (q >> 3) & 15, q & 1
-    th = ((q >> 11) << 6) | (((q >> 7) & 1) << 5) | (((q >> 10) & 1) << 4) | ((q >> 3) & 15)
+    th = (((q >> 3) & 15) << 6) | ((q >> 11) << 2) | (((q >> 10) & 1) << 1) | ((q >> 7) & 1)
     a = (((q >> 9) & 1) << 3) | (q & 7)
     return th, a, (q >> 8) & 1
 
