@@ -204,6 +204,7 @@ static int chan_close(void *p) {
 }
 static long chan_read(void *p, void *b, unsigned long n) {       /* whole int16 samples only */
   chan *c = p;
+  if (n < 2) return 0;
   pthread_mutex_lock(&c->mu);
   while (c->count < 2 && !c->closed) pthread_cond_wait(&c->can_read, &c->mu);
   size_t k = c->count & ~(size_t)1;
