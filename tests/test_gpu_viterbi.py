@@ -366,7 +366,10 @@ def test_split_stream_is_verified_and_exact(pkg, monkeypatch):
     comparison at a seam says -- pure noise with a short warm-up, or a forced mismatch -- the output is exact."""
     delay = 200
     for seed, nbits, noise_pct, warm, ndec, force in ((9400, 61200, 5, 14280, 2, False), (9401, 91800, 5, 8160, 3, False),
-                                                      (9402, 30600, 100, 2040, 2, False), (9403, 40800, 5, 14280, 2, True)):
+                                                      (9402, 30600, 100, 2040, 2, False), (9403, 40800, 5, 14280, 2, True),
+                                                      (9404, 5000, 5, 14280, 2, False),      # too short to split: one decoder
+                                                      (9405, 33333, 5, 4000, 2, False),      # ragged length, warm-up rounded up
+                                                      (9406, 25000, 5, 4080, 1, False)):     # ndec = 1
         syms, _ = orc.gen_coded_stream(seed, nbits, 2.5, 24.0, noise_pct)
         d = pkg.Viterbi224(delay + 2 * 1020)
         d.init(0)
