@@ -303,6 +303,38 @@ __global__ __launch_bounds__(64) void k_chainback_spec(const uint32_t *__restric
   }
 }
 
+// decodebit (port.c:124-141) with the same six-steps-per-round-trip speculation: walk `delay` rows back from dp with
+// ring wrap, return the last decision read.  (One call of the reference's per-bit pattern = one of these.)
+__global__ __launch_bounds__(64) void k_decodebit_spec(const uint32_t *__restrict__ rows,
+                                                       const uint32_t *__restrict__ rowmeta, int len, int dp,
+                                                       int delay, unsigned endstate, uint8_t *__restrict__ out) {
+  const unsigned lane = threadIdx.x;
+  const unsigned lvl = 31u - (unsigned)__clz((int)(lane + 1u));
+  const unsigned cand = lane + 1u - (1u << lvl);
+  unsigned st = endstate & V224_SMASK, last = 0;
+  int row = dp, remaining = delay;
+  while (remaining > 0) {
+    const int steps = remaining >= 6 ? 6 : remaining;
+    unsigned d = 0;
+    if (lane < 63u && (int)lvl < steps) {
+      int r = (row - 1 - (int)lvl) % len;
+      if (r < 0) r += len;
+      const unsigned cs = ((cand << (V224_SBITS - lvl)) | (st >> lvl)) & V224_SMASK;
+      d = get_decision(rows, rowmeta, r, cs);
+    }
+    unsigned c = 0;
+    for (int j = 0; j < steps; j++) {
+      last = (unsigned)__builtin_amdgcn_readlane((int)d, (int)((1u << j) - 1u + c));
+      c |= last << j;
+    }
+    st = ((c << (V224_SBITS - steps)) | (st >> steps)) & V224_SMASK;
+    row = (row - steps) % len;
+    if (row < 0) row += len;
+    remaining -= steps;
+  }
+  if (lane == 0) *out = (uint8_t)last;
+}
+
 // decodeword, sse2.c:206-243: result = bit<<63 | result>>1 per step
 __global__ void k_decodeword(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta,
                              int len, int dp, int delay, unsigned endstate,
@@ -726,8 +758,9 @@ extern "C" int decodebit_viterbi224(void *p, int delay, int endstate) {
   unsigned st = (unsigned)endstate;
   HIPCHK(hipSetDevice(v->dev));
   if (endstate < 0 && best_state(v, &st) != 0) return -1;
-  // steps_first is forced large: like the port, read whatever the ring holds
-  k_decodebits<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, v->dp, 1ull << 40, 1, delay, st, v->dmisc + 64);
+  // like the port, read whatever the ring holds
+  if (getenv("V224HIP_SERIAL_CHAINBACK")) k_decodebits<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, v->dp, 1ull << 40, 1, delay, st, v->dmisc + 64);
+  else k_decodebit_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, v->dp, delay, st, v->dmisc + 64);
   HIPCHK(hipMemcpyAsync(&bit, v->dmisc + 64, 1, hipMemcpyDeviceToHost, v->st));
   HIPCHK(hipStreamSynchronize(v->st));
   return bit;
