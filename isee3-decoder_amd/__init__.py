@@ -485,3 +485,8 @@ def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=2
     if rc != 0:
         raise RuntimeError("isee3_chain_run_mem: " + (L.isee3_chain_last_error() or b"").decode())
     return out.raw[:n.value]
+
+
+def release_chain_objects():
+    """isee3_chain_release(): free the decoder / pmdemod / symdemod objects the chain library keeps between calls."""
+    chain_lib().isee3_chain_release()

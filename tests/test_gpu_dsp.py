@@ -295,3 +295,17 @@ def test_vdecode_cli_file_input_uses_both_decoders_same_output(pkg, tmp_path):
         filed = subprocess.run([exe, "-q"], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert piped.returncode == 0 and filed.returncode == 0, filed.stderr
     assert len(piped.stdout) > 99_000 and piped.stdout == filed.stdout
+
+
+def test_chain_objects_are_reused_and_released(pkg):
+    """libisee3chain.so keeps its decoder / pmdemod / symdemod objects between calls (a kept pmdemod handle must not
+    carry the previous call's de-chirp table or state): three calls, two settings, same answers as fresh; then release."""
+    fs = 16384.0
+    iq, _ = orc.gen_iq(4301, fs, 3.2, fc_hz=987.6, amp=3000.0, cn0_dbhz=50.0)
+    first = pkg.run_chain(iq, samprate=fs, binsize=4.0, symrate="1024")
+    other = pkg.run_chain(iq, samprate=fs, binsize=8.0, symrate="1024")          # another FFT size: another handle
+    again = pkg.run_chain(iq, samprate=fs, binsize=4.0, symrate="1024")
+    assert again == first and len(first) > 800 and len(other) > 800
+    pkg.release_chain_objects()
+    assert pkg.run_chain(iq, samprate=fs, binsize=4.0, symrate="1024") == first
+    pkg.release_chain_objects()
