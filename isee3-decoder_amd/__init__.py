@@ -478,7 +478,13 @@ def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=2
     o.samprate, o.binsize, o.decode_delay, o.flip = samprate, binsize, decode_delay, int(flip)
     o.search_freq, o.search_width = search_freq, search_width
     o.symrate = None if symrate is None else str(symrate).encode()
-    cap = int(len(iq) / 2 / samprate * 1100) + 4096
+    # decoded bits <= symbols / 2; symbols = duration x the rate `symdemod -c` resolves to (symdemod.c:67-77).  10 % and
+    # 4 KiB of head room; the library reports a short write as an error instead of truncating.
+    if symrate is None:
+        rate = 1024.545058
+    else:
+        rate = float(symrate) if "." in str(symrate) else float(symrate) * 1024.545058 / 1024.0
+    cap = min(len(iq) // 4 + 4096, int(len(iq) / 2 / samprate * rate / 2 * 1.1) + 4096)
     out = C.create_string_buffer(cap)
     n = C.c_size_t(0)
     rc = L.isee3_chain_run_mem(C.byref(o), iq.ctypes.data, len(iq) // 2, out, cap, C.byref(n))

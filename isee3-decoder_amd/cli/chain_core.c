@@ -94,7 +94,14 @@ static void sy_destroy(void *p) {
   free(c);
 }
 
+/* stream chunk of the decoders (bits): read from the environment ONCE, before any chain thread exists */
 static int g_chunk = 1020;
+static pthread_once_t g_chunk_once = PTHREAD_ONCE_INIT;
+static void chunk_from_env(void) {
+  const char *e = getenv("V224HIP_CHUNK");
+  int c = e ? atoi(e) : 1020;
+  g_chunk = c < 8 ? 1020 : c;
+}
 /* vdecode engine: one decoder for block-wise streaming; for one long stream (whole-input mode) a second decoder joins
  * and the stream is decoded in two halves at once, verified at the seam (v224hip_stream_decode_split) */
 typedef struct { void *d[2]; int len; } vd_ctx;
@@ -266,21 +273,14 @@ static int chain_run(const isee3_chain_opts *co, FILE *in, FILE *out, int finite
   pa.o.argv0 = "isee3chain/pmdemod"; sa.o.argv0 = "isee3chain/symdemod"; va.o.argv0 = "isee3chain/vdecode";
   pa.o.samprate = co->samprate; sa.o.samprate = (int)co->samprate;
   pa.o.binsize = co->binsize; pa.o.search_freq = co->search_freq; pa.o.search_width = co->search_width; pa.o.flip = co->flip;
-  if (co->symrate) {                                  /* symdemod -c semantics (symdemod.c:67-77) */
-    char buf[64]; snprintf(buf, sizeof buf, "%s", co->symrate);
-    char *av[3] = { "symdemod", "-c", buf };
-    symdemod_opts t; int keep = optind;
-    symdemod_parse_args(&t, 3, av);
-    sa.o.symrate = t.symrate; sa.o.symbolclocks = t.symbolclocks; optind = keep;
-  }
+  if (co->symrate) symdemod_set_symrate(&sa.o, co->symrate);   /* symdemod -c semantics; no getopt in a library that runs concurrent chains */
   va.o.decode_delay = co->decode_delay;
   /* a capture in memory is finite and nobody waits for early bits: let vdecode see the whole symbol stream at once.
    * ISEE3_CHAIN_WHOLE=0 / 1 overrides. */
   (void)finite_input;   /* measured: at 30 k bits per capture the second decoder and the lost overlap with pmdemod/symdemod cost more than the split saves (72 vs 57 ms) */
   va.o.whole_input = getenv("ISEE3_CHAIN_WHOLE") ? atoi(getenv("ISEE3_CHAIN_WHOLE")) : 0;
   pa.o.quiet = sa.o.quiet = va.o.quiet = !co->verbose;
-  if (getenv("V224HIP_CHUNK")) g_chunk = atoi(getenv("V224HIP_CHUNK"));
-  if (g_chunk < 8) g_chunk = 1020;
+  pthread_once(&g_chunk_once, chunk_from_env);
   if (!c1 || pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() / channel allocation failed"); chan_free(c1); return 2; }
 #ifdef F_SETPIPE_SZ
   fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);

@@ -17,6 +17,13 @@ void symdemod_default_opts(symdemod_opts *o) {
   o->argv0 = "symdemod";
 }
 
+/* the -c rule, symdemod.c:67-77: no decimal point = a nominal rate, scaled to the measured spacecraft clock */
+void symdemod_set_symrate(symdemod_opts *o, const char *arg) {
+  if (!strchr(arg, '.')) o->symrate = atof(arg) * ACTUALCLOCK / NOMINALCLOCK;
+  else o->symrate = atof(arg);
+  if (o->symrate < 1000) o->symbolclocks = (int)rint(NOMINALCLOCK / o->symrate);
+}
+
 int symdemod_parse_args(symdemod_opts *o, int argc, char **argv) {
   int c;
   symdemod_default_opts(o);
@@ -27,12 +34,7 @@ int symdemod_parse_args(symdemod_opts *o, int argc, char **argv) {
     case 't': o->clocktrack = 1; break;
     case 'w': o->window = atof(optarg); break;
     case 'q': o->quiet = 1; break;
-    case 'c':
-      /* no decimal point: a nominal rate, scaled to the measured spacecraft clock (symdemod.c:68-73) */
-      if (!strchr(optarg, '.')) o->symrate = atof(optarg) * ACTUALCLOCK / NOMINALCLOCK;
-      else o->symrate = atof(optarg);
-      if (o->symrate < 1000) o->symbolclocks = (int)rint(NOMINALCLOCK / o->symrate);
-      break;
+    case 'c': symdemod_set_symrate(o, optarg); break;
     case 'r': o->samprate = atoi(optarg); break;
     case 'C': o->symbolclocks = atoi(optarg); break;
     default: break;

@@ -28,6 +28,8 @@ typedef struct {
 
 void symdemod_default_opts(symdemod_opts *o);
 int  symdemod_parse_args(symdemod_opts *o, int argc, char **argv);
+/* the -c argument rule (symdemod.c:67-77) on its own: pure, no getopt -- for callers inside a library */
+void symdemod_set_symrate(symdemod_opts *o, const char *arg);
 int  symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, FILE *out, FILE *err);
 /* the same stage reading through rd(ctx, buf, nbytes) (read(2) semantics: > 0 bytes, 0 at end of input) instead
  * of a file descriptor -- the in-process chain hands blocks over in memory */

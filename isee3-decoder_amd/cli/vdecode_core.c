@@ -90,8 +90,9 @@ static size_t pass1(const vdecode_opts *o, p1_state *st, const unsigned char *in
   return np;
 }
 
-/* start-up suppression, output, re-encode statistics, status lines for pairs [j0, j1) (vdecode.c:151-184) */
-static void pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec, const unsigned char *hard,
+/* start-up suppression, output, re-encode statistics, status lines for pairs [j0, j1) (vdecode.c:151-184).
+ * -1 when the engine handed back something that is not a bit once start-up is over, or the output cannot be written */
+static int pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec, const unsigned char *hard,
                   size_t j0, size_t j1, const flip_event *fl, size_t nfl, size_t *f, char *obuf, FILE *out, FILE *err) {
   size_t no = 0;
   for (size_t j = j0; j < j1; j++) {
@@ -100,7 +101,8 @@ static void pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec,
       if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0);
     }
     if (st->startup == 0) {
-      unsigned bit = dec[j] & 1u;
+      if (dec[j] > 1u) { fprintf(err, "%s: decoder engine returned no bit for trellis step %zu\n", o->argv0, j); return -1; }
+      unsigned bit = dec[j];
       obuf[no++] = bit ? '1' : '0';
       st->reenc = (st->reenc << 1) | bit;
     } else st->startup--;
@@ -116,8 +118,12 @@ static void pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec,
       st->symerrs = 0;
     }
   }
-  if (no) { fwrite(obuf, 1, no, out); fflush(out); }
+  if (no && (fwrite(obuf, 1, no, out) != no || fflush(out) != 0)) {
+    fprintf(err, "%s: short write on the output\n", o->argv0);
+    return -1;
+  }
   st->bits_out += no;
+  return 0;
 }
 
 int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE *out, FILE *err,
@@ -157,7 +163,7 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
       size_t np = pass1(o, &s1, inbuf, (size_t)got, delay, syms, hard, 0, fl, &nfl);
       /* the engine: np trellis steps, one traceback each */
       if (np && e->stream_decode(vd, syms, (int)np, delay, dec) != 0) goto done;
-      pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err);
+      if (pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err) != 0) goto done;
       while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
     }
   } else {
@@ -184,7 +190,7 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
     free(obuf); obuf = malloc(np + 1);
     if (!dec || !obuf) goto done;
     if (np && e->stream_decode_whole(vd, syms, (long long)np, delay, dec) != 0) goto done;
-    pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err);
+    if (pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err) != 0) goto done;
     while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
   }
   rc = 0;

@@ -81,6 +81,11 @@ struct V224 {
   std::vector<EvPair> ev_busy, ev_free;
   unsigned long long prof_launches, prof_steps; double prof_ms;
   hipEvent_t ev_acs[2], ev_tb[2];
+  // kept between calls (grow-only, freed by delete): seam snapshots of stream_decode_split ([0] as the earlier decoder
+  // "A" of a seam, [1] as the later one "B"), their events, the warm-up output nobody reads
+  uint16_t *snap[2]; hipEvent_t ev_snap[2];
+  uint8_t *warmout; size_t warmout_cap;
+  size_t dsyms_off;         // update_viterbi224_blk: next free byte of dsyms (symbols of queued launches stay put)
 };
 
 static int g_device = -1;
@@ -546,6 +551,8 @@ extern "C" void delete_viterbi224(void *p) {
   }
   (void)hipFree(v->m[0]); (void)hipFree(v->m[1]); (void)hipFree(v->rows); (void)hipFree(v->rowmeta);
   (void)hipFree(v->ds); (void)hipFree(v->dsyms); (void)hipFree(v->dout); (void)hipFree(v->dmisc);
+  (void)hipFree(v->snap[0]); (void)hipFree(v->snap[1]); (void)hipFree(v->warmout);
+  for (int i = 0; i < 2; i++) if (v->ev_snap[i]) (void)hipEventDestroy(v->ev_snap[i]);
   if (v->st) (void)hipStreamDestroy(v->st);
   if (v->st2) (void)hipStreamDestroy(v->st2);
   delete v;
@@ -716,14 +723,24 @@ extern "C" int update_viterbi224_blk(void *p, const unsigned char *syms, int nbi
   if (!v) return -1;
   if (nbits <= 0) return 0;
   HIPCHK(hipSetDevice(v->dev));
-  // the previous H2D into dsyms may still be feeding queued launches: drain before reuse
-  HIPCHK(hipStreamSynchronize(v->st));
-  if (ensure_cap(&v->dsyms, &v->dsyms_cap, 2 * (size_t)nbits) != 0) {
-    snprintf(g_err, sizeof g_err, "update: device symbol buffer allocation failed");
-    return -1;
+  {
+    // Symbols of launches that are still queued must stay where they are.  Calls bump-allocate from a staging
+    // buffer (at least 64 KiB: 16 384 of the reference's one-bit calls, vdecode.c:145) and the stream is only
+    // drained when the buffer wraps or has to grow -- not on every call.
+    const size_t need = (2 * (size_t)nbits + 3) & ~(size_t)3;
+    if (v->dsyms_off + need > v->dsyms_cap) {
+      HIPCHK(hipStreamSynchronize(v->st));
+      if (ensure_cap(&v->dsyms, &v->dsyms_cap, need < (64u << 10) ? (64u << 10) : need) != 0) {
+        snprintf(g_err, sizeof g_err, "update: device symbol buffer allocation failed");
+        return -1;
+      }
+      v->dsyms_off = 0;
+    }
+    uint8_t *dst = v->dsyms + v->dsyms_off;
+    v->dsyms_off += need;
+    HIPCHK(hipMemcpyAsync(dst, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice, v->st));
+    if (enqueue_acs(v, dst, nbits) != 0) return -1;
   }
-  HIPCHK(hipMemcpyAsync(v->dsyms, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice, v->st));
-  if (enqueue_acs(v, v->dsyms, nbits) != 0) return -1;
   return 0;                                          // port convention (port.c:194)
 fail:
   return -1;
@@ -810,7 +827,7 @@ fail:
 // frame's ACS.  Nothing synchronises with the host until all frames are enqueued.
 extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint8_t *syms, int nframes,
                                      int framebits, int startstate, unsigned int endstate, uint8_t *out) {
-  uint8_t *d_syms = nullptr, *d_out = nullptr;
+  uint8_t *d_syms = nullptr, *d_out = nullptr;       // = decoder 0's staging buffers
   if (!decoders || ndec <= 0 || nframes < 0 || framebits <= 0 || !syms || !out) {
     snprintf(g_err, sizeof g_err, "decode_frames: bad argument");
     return -1;
@@ -827,10 +844,17 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
       }
     }
     HIPCHK(hipSetDevice(v0->dev));
-    HIPCHK(hipMalloc(&d_syms, symbytes * nframes));
-    HIPCHK(hipMalloc(&d_out, outbytes * nframes));
-    HIPCHK(hipMemcpy(d_syms, syms, symbytes * nframes, hipMemcpyHostToDevice));
+    // staging lives in decoder 0 (grow-only, kept between calls): no hipMalloc / hipFree per batch
     for (int i = 0; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
+    if (ensure_cap(&v0->dsyms, &v0->dsyms_cap, symbytes * nframes) != 0 || ensure_cap(&v0->dout, &v0->dout_cap, outbytes * nframes) != 0) {
+      snprintf(g_err, sizeof g_err, "decode_frames: device staging allocation failed");
+      return -1;
+    }
+    v0->dsyms_off = v0->dsyms_cap;
+    d_syms = v0->dsyms; d_out = v0->dout;
+    HIPCHK(hipMemcpyAsync(d_syms, syms, symbytes * nframes, hipMemcpyHostToDevice, v0->st));
+    HIPCHK(hipEventRecord(v0->ev_acs[0], v0->st));
+    for (int i = 1; i < ndec; i++) HIPCHK(hipStreamWaitEvent(((V224 *)decoders[i])->st, v0->ev_acs[0], 0));
     for (int f = 0; f < nframes; f++) {
       V224 *v = (V224 *)decoders[f % ndec];
       if (init_viterbi224(v, startstate) != 0) goto fail;
@@ -838,15 +862,13 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
       k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f);
     }
     HIPCHK(hipGetLastError());
-    for (int i = 0; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
-    HIPCHK(hipMemcpy(out, d_out, outbytes * nframes, hipMemcpyDeviceToHost));
+    for (int i = 1; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
+    HIPCHK(hipMemcpyAsync(out, d_out, outbytes * nframes, hipMemcpyDeviceToHost, v0->st));
+    HIPCHK(hipStreamSynchronize(v0->st));
   }
-  (void)hipFree(d_syms); (void)hipFree(d_out);
   return 0;
 fail:
   for (int i = 0; i < ndec; i++) if (decoders[i]) (void)hipStreamSynchronize(((V224 *)decoders[i])->st);
-  if (d_syms) (void)hipFree(d_syms);
-  if (d_out) (void)hipFree(d_out);
   return -1;
 }
 
@@ -943,10 +965,7 @@ struct SplitItem { long long bit0; long long nbits; uint8_t *out; int snap; };  
 
 extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
                                            uint8_t *d_out, int warm_bits, int *nfallback) {
-  uint16_t *snapA[8] = {nullptr}, *snapB[8] = {nullptr};
-  uint8_t *scratch[8] = {nullptr};
   unsigned *d_cnt = nullptr, h_cnt[8] = {0};
-  hipEvent_t evA[8] = {nullptr}, evB[8] = {nullptr};
   int rc = -1, fb = 0;
   if (nfallback) *nfallback = 0;
   if (!decoders || ndec < 1 || ndec > 8 || !d_syms || !d_out || nbits < 0 || delay <= 0) {
@@ -961,9 +980,15 @@ extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, cons
       return -1;
     }
   }
-  const long long chunk = v0->chunk, check = chunk;
+  // The seam window.  Decoder j's metrics are compared with decoder j-1's after trellis step start[j] - check; equal
+  // (up to a constant) metrics make every decision row written AFTER that step identical in both.  The first
+  // traceback of part j walks `delay` rows back from step start[j] + 1, so all rows it reads are such rows iff
+  // check >= delay - 1: check = delay rounded up to whole chunks.  (The reference allows any -d, vdecode.c:86-91.)
+  const long long chunk = v0->chunk, check = ((long long)delay + chunk - 1) / chunk * chunk;
+  // warm = check + the bits given to forgetting the fresh start (at least two chunks); `warm_bits` counts both, as the
+  // header says, and is raised when a long delay leaves too little of it for forgetting
   long long warm = ((long long)warm_bits + chunk - 1) / chunk * chunk;
-  if (warm < 2 * chunk) warm = 2 * chunk;
+  if (warm < check + 2 * chunk) warm = check + 2 * chunk;
   // parts: equal finishing times => part 0 is `warm` longer than the others' own share
   int P = ndec;
   while (P > 1 && ((long long)nbits + (P - 1) * warm) / P / chunk * chunk < warm + chunk) P--;     // too short to split that far
@@ -975,25 +1000,33 @@ extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, cons
     start[P] = nbits;
   }
   HIPCHK(hipSetDevice(v0->dev));
-  if (P > 1) {
-    HIPCHK(hipMalloc(&d_cnt, 8 * sizeof(unsigned)));
-    HIPCHK(hipMemset(d_cnt, 0, 8 * sizeof(unsigned)));
+  // seam resources live in the decoder objects (allocated on first use, kept until delete): decoder j holds the
+  // snapshot it takes as the LATER side ("B") of seam j in snap[1] and as the EARLIER side ("A") of seam j+1 in snap[0]
+  for (int j = 0; j < P && P > 1; j++) {
+    V224 *v = (V224 *)decoders[j];
+    for (int w = 0; w < 2; w++) {
+      if ((w == 0 && j == P - 1) || (w == 1 && j == 0)) continue;
+      if (!v->snap[w]) HIPCHK(hipMalloc(&v->snap[w], sizeof(uint16_t) * V224_NSTATES));
+      if (!v->ev_snap[w]) HIPCHK(hipEventCreateWithFlags(&v->ev_snap[w], hipEventDisableTiming));
+    }
+    if (j > 0 && ensure_cap(&v->warmout, &v->warmout_cap, (size_t)warm) != 0) {
+      snprintf(g_err, sizeof g_err, "stream_decode_split: warm-up buffer allocation failed");
+      return -1;
+    }
   }
-  for (int j = 1; j < P; j++) {
-    HIPCHK(hipMalloc(&snapA[j], sizeof(uint16_t) * V224_NSTATES));
-    HIPCHK(hipMalloc(&snapB[j], sizeof(uint16_t) * V224_NSTATES));
-    HIPCHK(hipMalloc(&scratch[j], (size_t)warm));
-    HIPCHK(hipEventCreateWithFlags(&evA[j], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&evB[j], hipEventDisableTiming));
+  if (P > 1) {
+    d_cnt = (unsigned *)(v0->dmisc + 1024);
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned), v0->st));
   }
   {
     // work lists: decoder j warms up from start[j] - warm, snapshots at the checkpoint start[j] - check (as B of seam j),
     // decodes its part, and snapshots at start[j+1] - check on the way (as A of seam j+1)
     std::vector<SplitItem> work[8];
     for (int j = 0; j < P; j++) {
+      V224 *v = (V224 *)decoders[j];
       if (j > 0) {
-        work[j].push_back({start[j] - warm, warm - check, scratch[j], -j});
-        work[j].push_back({start[j] - check, check, scratch[j] + (warm - check), 0});
+        work[j].push_back({start[j] - warm, warm - check, v->warmout, -j});
+        work[j].push_back({start[j] - check, check, v->warmout + (warm - check), 0});
       }
       if (j < P - 1) {
         work[j].push_back({start[j], start[j + 1] - check - start[j], d_out + start[j], j + 1});
@@ -1015,25 +1048,26 @@ extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, cons
         done[j] += n;
         if (done[j] >= w.nbits) {
           if (w.snap != 0) {
-            const int seam = w.snap > 0 ? w.snap : -w.snap;
             ensure_layout(v, 1);                       // both sides of a seam are compared in the same (tile) order
             ensure_min_valid(v);
-            k_snapshot_rel<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, w.snap > 0 ? snapA[seam] : snapB[seam]);
-            HIPCHK(hipEventRecord(w.snap > 0 ? evA[seam] : evB[seam], v->st));
+            const int side = w.snap > 0 ? 0 : 1;
+            k_snapshot_rel<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, v->snap[side]);
+            HIPCHK(hipEventRecord(v->ev_snap[side], v->st));
           }
           it[j]++; done[j] = 0;
         }
       }
     }
     for (int j = 1; j < P; j++) {                       // all snapshots are enqueued: compare
-      HIPCHK(hipStreamWaitEvent(v0->st, evA[j], 0));
-      HIPCHK(hipStreamWaitEvent(v0->st, evB[j], 0));
-      k_count_diff<<<V224_NSTATES / 8 / 256, 256, 0, v0->st>>>(reinterpret_cast<const uint4 *>(snapA[j]),
-                                                                reinterpret_cast<const uint4 *>(snapB[j]), d_cnt + j);
+      V224 *va = (V224 *)decoders[j - 1], *vb = (V224 *)decoders[j];
+      HIPCHK(hipStreamWaitEvent(v0->st, va->ev_snap[0], 0));
+      HIPCHK(hipStreamWaitEvent(v0->st, vb->ev_snap[1], 0));
+      k_count_diff<<<V224_NSTATES / 8 / 256, 256, 0, v0->st>>>(reinterpret_cast<const uint4 *>(va->snap[0]),
+                                                                reinterpret_cast<const uint4 *>(vb->snap[1]), d_cnt + j);
     }
     HIPCHK(hipGetLastError());
+    if (P > 1) HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, v0->st));
     for (int j = 0; j < P; j++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[j])->st));
-    if (P > 1) HIPCHK(hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost));
     if (P > 1 && getenv("V224HIP_SPLIT_FORCE_FALLBACK")) h_cnt[P - 1] = 1;         // test hook: exercise the redo path
     for (int j = 1; j < P; j++) {
       if (h_cnt[j] == 0) continue;
@@ -1048,14 +1082,7 @@ extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, cons
   if (nfallback) *nfallback = fb;
   rc = 0;
 fail:
-  for (int j = 0; j < 8; j++) {
-    if (snapA[j]) (void)hipFree(snapA[j]);
-    if (snapB[j]) (void)hipFree(snapB[j]);
-    if (scratch[j]) (void)hipFree(scratch[j]);
-    if (evA[j]) (void)hipEventDestroy(evA[j]);
-    if (evB[j]) (void)hipEventDestroy(evB[j]);
-  }
-  if (d_cnt) (void)hipFree(d_cnt);
+  if (rc != 0) for (int j = 0; j < ndec; j++) if (decoders[j]) (void)hipStreamSynchronize(((V224 *)decoders[j])->st);
   return rc;
 }
 
@@ -1066,6 +1093,7 @@ extern "C" int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, in
   HIPCHK(hipSetDevice(v->dev));
   HIPCHK(hipStreamSynchronize(v->st));
   if (ensure_cap(&v->dsyms, &v->dsyms_cap, 2 * (size_t)nbits) != 0) return -1;
+  v->dsyms_off = v->dsyms_cap;                      // the whole buffer is in use until the next drain
   if (ensure_cap(&v->dout, &v->dout_cap, (size_t)nbits) != 0) return -1;
   HIPCHK(hipMemcpyAsync(v->dsyms, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice, v->st));
   if (v224hip_stream_decode_dev(p, v->dsyms, nbits, delay, v->dout) != 0) return -1;

@@ -22,10 +22,15 @@ def plan_segments(nblocks, nseg, warm_blocks):
     return [(max(0, edges[i] - warm_blocks), edges[i], edges[i + 1]) for i in range(nseg) if edges[i + 1] > edges[i]]
 
 
-def stitch(parts, overlap_bits, probe_len=160):
+def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=400, settled=2300):
     """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments;
-    overlap_bits[i]: roughly how many decoded bits part i+1 shares with part i (its warm-up region).
-    A probe is taken from the settled end of that region and located in the previous part.
+    overlap_bits[i]: how many decoded bits lie between the start of part i+1 and the cut (its warm-up region).
+    A probe is taken from the settled end of that region and located in the previous part -- but only where it
+    can be: part i ends `tail_bits` = (min, max) bits short of the cut (vdecode holds back `delay` bits, symdemod
+    drops the last partial window), so bit w of part i+1 sits at len(part i) + tail - (overlap - w).  The probe must
+    occur exactly ONCE in that range (repetitive telemetry can match one frame off), and with that alignment the two
+    parts must agree on EVERYTHING they share from up to `verify_back` bits before the probe (not before the part's
+    `settled` bit) to the end of part i; otherwise the seam counts as unmatched.
     Returns (joined bits, seams matched, seams total)."""
     out = parts[0]
     ok = 0
@@ -34,19 +39,26 @@ def stitch(parts, overlap_bits, probe_len=160):
         # the first ~2300 bits of a restarted decode are unreliable: start-up delay, and vdecode decides its
         # symbol-pair phase only once per 2048 ODD symbols = two frames (vdecode.c:122-139).  Probe between
         # there and the end of the overlap.
-        for w in range(max(2300, ovl - 300), 2200, -100):
+        for w in range(max(settled, ovl - 300), settled - 100, -100):
             probe = nxt[w:w + probe_len]
             if len(probe) < probe_len:
                 continue
-            p = out.rfind(probe)
-            if p >= 0:
-                out = out[:p] + nxt[w:]
-                placed = True
-                break
+            expect = len(out) - (ovl - w)
+            lo = max(0, expect + tail_bits[0] - 64)
+            hi = min(len(out), expect + tail_bits[1] + 64 + probe_len)
+            p = out.find(probe, lo, hi)
+            if p < 0 or out.find(probe, p + 1, hi) >= 0:
+                continue                                 # absent, or ambiguous inside the window
+            back = max(0, min(verify_back, w - settled, p))
+            if out[p - back:] != nxt[w - back:w - back + (len(out) - p + back)]:
+                continue                                 # the alignment does not hold over the rest of the overlap
+            out = out[:p] + nxt[w:]
+            placed = True
+            break
         if placed:
             ok += 1
         else:
-            out = out + nxt          # no exact match inside the overlap: keep everything, caller sees the count
+            out = out + nxt          # no verified match inside the overlap: keep everything, caller sees the count
     return out, ok, len(parts) - 1
 
 

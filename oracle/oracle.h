@@ -43,6 +43,7 @@ int   orc_v224_init(void *p, int starting_state);               /* port.c:34-48 
 int   orc_v224_update(void *p, const uint8_t *syms, int nbits); /* port.c:159-195 */
 int   orc_v224_chainback(void *p, uint8_t *data, unsigned nbits, unsigned endstate); /* port.c:72-101 */
 int   orc_v224_decodebit(void *p, int delay, int endstate);     /* port.c:104-143 */
+unsigned long long orc_v224_decodeword(void *p, int delay, int endstate);   /* sse2.c:206-243, on the port's decisions */
 void  orc_v224_delete(void *p);                                 /* port.c:146-153 */
 
 /* test introspection */

@@ -208,6 +208,39 @@ int orc_v224_decodebit(void *p, int delay, int endstate) {
   return bit;
 }
 
+/* viterbi224_sse2.c:206-243 (the port has no decodeword): best state by strict < from state 0 when end < 0, else
+ * end & 0xffffff; walk `delay` rows back from dp with ring wrap; result = bit << 63 | result >> 1 per step.
+ * The reference does not mask bit 23 of `end` (it would index past the decision row); here it is masked. */
+unsigned long long orc_v224_decodeword(void *p, int delay, int endstate) {
+  orc_v224 *v = p;
+  if (!v) return 0;
+  uint32_t st;
+  if (endstate < 0) {
+    st = 0;
+    if (v->mode == ORC_V224_LITERAL) {
+      const uint32_t *m = v->m32[v->cur];
+      uint32_t best = m[0];
+      for (uint32_t i = 1; i < NST; i++) if (m[i] < best) { best = m[i]; st = i; }
+    } else {
+      const uint16_t *m = v->m16[v->cur];
+      uint16_t ref = m[0]; int16_t best = 0;
+      for (uint32_t i = 1; i < NST; i++) {
+        int16_t r = (int16_t)(m[i] - ref);
+        if (r < best) { best = r; st = i; }
+      }
+    }
+  } else st = (uint32_t)endstate & 0xffffffu & MASK;
+  unsigned long long result = 0;
+  int row = v->dp;
+  while (delay-- > 0) {
+    if (--row < 0) row = v->len - 1;
+    unsigned bit = rowbit(v, row, st);
+    st = (bit << (ORC_K - 2)) | (st >> 1);
+    result = ((unsigned long long)bit << 63) | (result >> 1);
+  }
+  return result;
+}
+
 const uint8_t *orc_v224_row(void *p, int row) {
   orc_v224 *v = p;
   return v->rows + (size_t)row * ORC_ROWBYTES;

@@ -17,6 +17,10 @@ reference's own code run here:
   * decode_cli2.npz      the same driver through a noise burst (lock lost) and a 3-symbol slip, also with -n -r 512
   * decode_cli.npz       oracle/_ref/decode_port_ref (decode.c -V unmodified, port decoder) stdout: frame-sync
                          correlator + init(0x819fbe)/update(1024)/chainback per frame.
+  * decodeword_sse2.npz  viterbi224_sse2.c's decodeword / min_metric / max_metric (the port has none) on CLEAN
+                         coded streams, where the SSE2 and the port decoder take the same survivor path (F1).
+  * vdecode_stderr.npz   oracle/_ref/vdecode_port_ref stderr (status lines with the re-encode symbol-error tally,
+                         vdecode.c:159-184) for the vdecode_cli.npz inputs, -i 256.
   * pmdemod_oracle.npz   NOT from the reference (FFTW3 absent => pmdemod.c cannot be built): outputs
                          of this repo's restatement, kept only as a regression anchor.  UNPINNED.
 Fixtures hold data only: inputs (or the seed + sha256 of a regenerable input) and expected outputs.
@@ -264,7 +268,54 @@ def make_pmdemod():
     np.savez_compressed(os.path.join(HERE, "pmdemod_oracle.npz"), **flat)
 
 
-ALL = dict(framed=make_framed, stream=make_stream, vdecode=make_vdecode, symdemod=make_symdemod,
+def make_decodeword():
+    """a10: decodeword exists only in viterbi224_sse2.c.  Clean coded streams (Eb/N0 7 dB: no channel error reaches the
+    survivor), several delays and end states incl. the best-state search (end < 0)."""
+    flat = {"names": np.array(["clean_len300", "clean_wrap_len200"])}
+    for name, seed, nbits, length in (("clean_len300", 701, 300, 300), ("clean_wrap_len200", 702, 460, 200)):
+        syms, sent = orc.gen_coded_stream(seed, nbits, 7.0, 24.0, 0)
+        r = orc.RefV224(length, "sse2")
+        r.init(0)
+        r.update(syms, nbits)
+        q = [(64, 0), (64, -1), (17, -1), (1, 0), (100, -1), (min(length, nbits), -1), (64, 0x2aaaaa)]
+        words = np.array([r.decodeword(d, e) for d, e in q], dtype=np.uint64)
+        r.close()
+        flat[name + "/syms"], flat[name + "/sent"] = syms, sent
+        flat[name + "/nbits"], flat[name + "/length"] = nbits, length
+        flat[name + "/queries"] = np.array(q, dtype=np.int64)
+        flat[name + "/sse2_words"] = words
+        print("decodeword", name, [hex(int(w)) for w in words])
+    np.savez_compressed(os.path.join(HERE, "decodeword_sse2.npz"), **flat)
+
+
+def _vdecode_err_case(spec):
+    name, args, syms = spec
+    exe = os.path.join(orc.REF_DIR, "vdecode_port_ref")
+    import subprocess
+    p = subprocess.run([exe] + args, input=syms.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, LANG="C", LC_ALL="C"), check=True, timeout=3600)
+    return name, args, p.stdout, p.stderr
+
+
+def make_vdecode_stderr():
+    z = np.load(os.path.join(HERE, "vdecode_cli.npz"))
+    specs = []
+    for name in [str(n) for n in z["names"]]:
+        args = [a for a in z[name + "/args"] if a] + ["-i", "256"]
+        specs.append((name, args, z[name + "/syms"]))
+    with mp.Pool(len(specs)) as pool:
+        res = pool.map(_vdecode_err_case, specs)
+    flat = {"names": np.array([r[0] for r in res])}
+    for name, args, out, err in res:
+        assert out == z[name + "/stdout"].tobytes(), "stdout moved?"
+        flat[name + "/args"] = np.array(args, dtype="U8")
+        flat[name + "/stderr"] = np.frombuffer(err, dtype=np.uint8)
+        print("vdecode stderr", name)
+        print(err.decode())
+    np.savez_compressed(os.path.join(HERE, "vdecode_stderr.npz"), **flat)
+
+
+ALL = dict(decodeword=make_decodeword, vdecode_stderr=make_vdecode_stderr, framed=make_framed, stream=make_stream, vdecode=make_vdecode, symdemod=make_symdemod,
            pmdemod=make_pmdemod, decode=make_decode, decode2=make_decode2)
 
 if __name__ == "__main__":

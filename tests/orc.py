@@ -50,6 +50,8 @@ def lib():
         L.orc_v224_chainback.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_uint]
         L.orc_v224_decodebit.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_v224_delete.argtypes = [C.c_void_p]
+        L.orc_v224_decodeword.restype = C.c_uint64
+        L.orc_v224_decodeword.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_v224_row.restype = u8p
         L.orc_v224_row.argtypes = [C.c_void_p, C.c_int]
         L.orc_v224_dp.argtypes = [C.c_void_p]
@@ -157,6 +159,9 @@ class OracleV224(_V224Base):
         assert self.h
         self.length = length
 
+    def decodeword(self, delay, endstate=0):
+        return int(lib().orc_v224_decodeword(self.h, int(delay), int(endstate)))
+
     def row(self, r):
         return np.ctypeslib.as_array(lib().orc_v224_row(self.h, int(r)), shape=(ROWBYTES,))
 
@@ -199,6 +204,14 @@ class RefV224(_V224Base):
         self.h = L.create_viterbi224(int(length))
         assert self.h
         self.length = length
+        if variant == "sse2":                      # the port implements six of the nine functions
+            L.decodeword_viterbi224.restype = C.c_uint64
+            L.decodeword_viterbi224.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.max_metric_viterbi224.argtypes = [C.c_void_p]
+            L.min_metric_viterbi224.argtypes = [C.c_void_p]
+
+    def decodeword(self, delay, endstate=0):
+        return int(self.L.decodeword_viterbi224(self.h, int(delay), int(endstate)))
 
 
 # ------------------------------------------------------------------ generators

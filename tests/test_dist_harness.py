@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import numpy as np
+
 from conftest import ROOT, load_pkg
 
 
@@ -32,3 +34,39 @@ def test_two_rank_gloo_harness():
     assert r["world"] == 2 and r["segments"] == [[0, 2, 4], [1, 3, 5]]
     # rank 1 sleeps twice as long per segment: the reported time is the slow rank's
     assert r["dt_max"] >= 0.11 and r["dt_max"] >= r["dt_rank0"]
+
+
+def test_stitch_locates_the_seam_by_position_and_verifies_it():
+    """segment.stitch: the probe is only looked for where the overlap can be, must be unique there, and the two parts
+    must agree over the rest of the overlap; repetitive telemetry one frame off, or a corrupted overlap, is NOT a match."""
+    load_pkg()
+    from isee3_decoder_amd import segment
+    rng = np.random.default_rng(5)
+    full = bytes(rng.integers(48, 50, 24000, dtype=np.uint8))
+    ovl, cut = 3500, 9000
+    junk = bytes(rng.integers(48, 50, 2100, dtype=np.uint8))          # unsettled start of a restarted decode
+    for tail in (200, 450, 720):
+        p0 = full[:cut - tail]
+        p1 = junk + full[cut - ovl + 2100:18000]
+        out, ok, tot = segment.stitch([p0, p1], [ovl])
+        assert (ok, tot) == (1, 1) and out == full[:18000]
+    # three parts
+    p0, p1, p2 = full[:8700], junk + full[9000 - ovl + 2100:15600], junk + full[16000 - ovl + 2100:]
+    out, ok, tot = segment.stitch([p0, p1, p2], [ovl, ovl])
+    assert (ok, tot) == (2, 2) and out == full
+    # the same bits elsewhere in the previous part (the old whole-string rfind would have taken them): ignored
+    decoy = full[9000 - ovl + 3000:9000 - ovl + 3400]
+    p0d = full[:2000] + decoy + full[2400:8700]
+    out, ok, tot = segment.stitch([p0d, p1], [ovl])
+    assert ok == 1 and out[8700:] == full[8700:15600]
+    # a corrupted overlap: the probe may match somewhere, the verification does not -> reported as unmatched
+    bad = bytearray(p1)
+    for i in range(2300, 3400, 7):
+        bad[i] ^= 1
+    out, ok, tot = segment.stitch([p0, bytes(bad)], [ovl])
+    assert ok == 0 and len(out) == len(p0) + len(bad)
+    # periodic frames: alignment is decided by position, never a frame off
+    frame = bytes(rng.integers(48, 50, 1024, dtype=np.uint8))
+    per = frame * 24
+    out, ok, tot = segment.stitch([per[:9000 - 300], per[9000 - ovl:20000]], [ovl])
+    assert ok == 1 and out == per[:20000]

@@ -309,3 +309,59 @@ def test_chain_objects_are_reused_and_released(pkg):
     pkg.release_chain_objects()
     assert pkg.run_chain(iq, samprate=fs, binsize=4.0, symrate="1024") == first
     pkg.release_chain_objects()
+
+
+@pytest.mark.parametrize("name", [str(n) for n in np.load(os.path.join(orc.GOLDEN, "vdecode_stderr.npz"))["names"]])
+def test_vdecode_cli_symbol_error_statistic_matches_reference_stderr(pkg, name):
+    """bin/vdecode's stderr == the reference vdecode's (vdecode.c:159-184 re-encode tally every -i bits, the phase-flip
+    notice, the delay warning): fixture minted from oracle/_ref/vdecode_port_ref, C locale, program name stripped."""
+    from test_vdecode_host import status_lines
+    z = np.load(os.path.join(orc.GOLDEN, "vdecode_stderr.npz"))
+    for whole in ("0", "1"):
+        p = subprocess.run([pkg.cli_path("vdecode")] + [str(a) for a in z[name + "/args"]],
+                           input=np.load(VG)[name + "/syms"].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=600, env=dict(os.environ, LANG="C", LC_ALL="C", VDECODE_WHOLE=whole))
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert status_lines(p.stderr) == status_lines(z[name + "/stderr"].tobytes())
+        assert p.stdout == np.load(VG)[name + "/stdout"].tobytes()
+
+
+@pytest.mark.slow
+def test_config2_full_size_chain_equals_oracle_chain(pkg):
+    """BASELINE configs[2] at its own size: 60 s x 250 kS/s synthetic int16 IQ (bench.py's capture), 1 Hz bins
+    (N = 2^18, 57 blocks), 1024 sym/s Manchester, vdecode -d 200.  libisee3chain.so on the GPU == oracle pmdemod ->
+    oracle symdemod -> oracle vdecode, bit for bit (pmdemod leg UNPINNED: FFTW3 absent, see oracle/pmdemod_oracle.c;
+    where oracle/_ref travelled along, the REFERENCE's symdemod binary is run on the oracle baseband as well)."""
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+    fs = 250000.0
+    iq, sent = synth.iq_capture(3, fs, 60.0, amp=None)
+    assert len(iq) == 2 * 15_000_000
+    got = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024", decode_delay=200)
+    bb, _, rep, N = orc.pmdemod(iq, samprate=fs, binsize=1.0, want_pre=False)
+    assert N == 1 << 18 and len(rep) == 57
+    sy, _, _ = orc.symdemod(bb, samprate=int(fs), c_opt="1024")
+    if orc.have_ref():
+        assert orc.ref_cli("symdemod_ref", ["-q", "-r", str(int(fs)), "-c", "1024"], bb.tobytes()) == sy.tobytes()
+    want, _ = orc.vdecode(sy)
+    assert len(want) > 29000
+    assert got == want
+    # and the decoded bits are the sent telemetry (after vdecode has settled its symbol-pair phase)
+    s = "".join(map(str, sent))
+    assert got[-1100:-100].decode() in s
+
+
+def test_config4_form_64_overlapped_segments(pkg):
+    """BASELINE configs[4] form at a shortened capture: ONE capture cut into 64 block-aligned segments, each extended to
+    the left by a 7-block warm-up, decoded independently (two chains at a time on this GPU) and stitched: all 63 seams
+    verified, result == the single-pass decode of the same capture."""
+    from importlib import import_module
+    seg = import_module("isee3_decoder_amd.segment")
+    fs = 16384.0
+    iq, sent = orc.gen_iq(97, fs, 64.5, fc_hz=-2222.2, amp=3000.0, cn0_dbhz=50.0)
+    single = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
+    bits, ok, seams, processed = seg.decode_segmented(iq, fs, 1.0, 64, pkg.run_chain, warm_blocks=7, concurrency=2)
+    assert seams == 63 and ok == 63
+    n = min(len(bits), len(single))
+    assert n > 30000 and bits[:n - 64] == single[:n - 64]
+    assert processed > 7 * 64 * 16384 * 0.8                    # every segment really carried its warm-up

@@ -413,3 +413,111 @@ def test_split_equals_single_at_full_bench_size(pkg):
     assert np.array_equal(d2.to_numpy(np.uint8), one)
     for x in decs:
         x.close()
+
+
+DW = os.path.join(orc.GOLDEN, "decodeword_sse2.npz")
+
+
+@pytest.mark.parametrize("engine,k", [(0, 0), (1, 6), (2, 0), (3, 0)], ids=["simple", "fused6", "lds8", "lds15"])
+def test_decodeword_vs_sse2_reference_fixture(pkg, engine, k):
+    """decodeword_viterbi224 against words minted from the reference's viterbi224_sse2.c:206-243 (the only
+    file that implements it) on clean coded streams -- where the SSE2 and the port decoder keep the same survivor --
+    incl. the best-state search (end < 0), delays 1..len and a wrapped ring."""
+    z = np.load(DW)
+    for name in [str(n) for n in z["names"]]:
+        nbits, length = int(z[name + "/nbits"]), int(z[name + "/length"])
+        d = pkg.Viterbi224(length, engine, k)
+        d.init(0)
+        d.update(z[name + "/syms"], nbits)
+        got = [d.decodeword(int(dl), int(e)) for dl, e in z[name + "/queries"]]
+        assert got == [int(w) for w in z[name + "/sse2_words"]], name
+        d.close()
+    if orc.have_ref():                 # the reference library itself, where oracle/_ref travelled along
+        syms, _ = orc.gen_coded_stream(9601, 400, 7.0, 24.0, 0)
+        r = orc.RefV224(256, "sse2")
+        d = pkg.Viterbi224(256, engine, k)
+        for x in (r, d):
+            x.init(0)
+            x.update(syms, 400)
+        for dl, e in ((64, 0), (64, -1), (200, -1), (3, 0x123456)):
+            assert d.decodeword(dl, e) == r.decodeword(dl, e)
+        r.close()
+        d.close()
+
+
+@pytest.mark.parametrize("engine,k", [(0, 0), (1, 5), (2, 0), (3, 0)], ids=["simple", "fused5", "lds8", "lds15"])
+def test_decodeword_vs_oracle_on_noisy_streams(pkg, engine, k):
+    """the same function where ties and unmerged paths matter: noisy stream with pure-noise blocks, against the oracle's
+    restatement of sse2.c:206-243 on the port's decisions (pinned by test_oracle_decodeword_matches_sse2_reference...)"""
+    nbits, length = 700, 320                                   # the ring wraps twice
+    syms, _ = orc.gen_coded_stream(9602, nbits, 1.0, 24.0, 30)
+    o = orc.OracleV224(length, orc.FAST)
+    d = pkg.Viterbi224(length, engine, k)
+    for x in (o, d):
+        x.init(0)
+    pos = 0
+    for piece in (1, 14, 15, 16, 300, 354):                    # words are asked for at ragged positions
+        o.update(syms[2 * pos:2 * (pos + piece)], piece)
+        d.update(syms[2 * pos:2 * (pos + piece)], piece)
+        pos += piece
+        for dl, e in ((64, 0), (64, -1), (min(pos, length), -1), (1, -1), (33, 0x7fffff)):
+            if dl <= min(pos, length):
+                assert d.decodeword(dl, e) == o.decodeword(dl, e), (pos, dl, e)
+    assert pos == nbits
+    o.close()
+    d.close()
+
+
+def test_split_with_long_decode_delays(pkg):
+    """vdecode allows any -d (vdecode.c:86-91 only warns above 1024).  The seam window of the split decode must cover
+    the traceback depth: delays of 1024 (three rows past one chunk), 1500, and one longer than the requested warm-up
+    all give exactly the single decoder's output, 0xff start-up marks included."""
+    for seed, nbits, delay, warm in ((9410, 40800, 1024, 14280), (9411, 51000, 1500, 14280), (9412, 61200, 5000, 4080),
+                                     (9413, 30600, 1021, 2040)):
+        syms, _ = orc.gen_coded_stream(seed, nbits, 2.5, 24.0, 5)
+        d = pkg.Viterbi224(delay + 2 * 1020)
+        d.init(0)
+        want = d.stream_decode(syms, delay)
+        d.close()
+        decs = [pkg.Viterbi224(delay + 2 * 1020) for _ in range(2)]
+        dsy, dout = pkg.DeviceBuffer.from_numpy(syms), pkg.DeviceBuffer(nbits)
+        nfb = pkg.stream_decode_split(decs, dsy, nbits, delay, dout, warm_bits=warm)
+        got = dout.to_numpy(np.uint8)
+        assert np.array_equal(got, want), "delay %d" % delay
+        assert np.all(got[delay:] <= 1) and nfb == 0
+        # a second call on the same decoder objects reuses their seam buffers
+        assert pkg.stream_decode_split(decs, dsy, nbits, delay, dout, warm_bits=warm) == 0
+        assert np.array_equal(dout.to_numpy(np.uint8), want)
+        for x in decs:
+            x.close()
+
+
+@pytest.mark.parametrize("tail", [0, 2], ids=["size_4k_multiple", "size_4k_plus_2"])
+def test_symbols_ending_at_the_last_byte_of_an_allocation(pkg, tail):
+    """the 15-step kernel fetches its 30 symbols as aligned dwords; the last pass of a buffer that ends exactly at its
+    allocation's last byte must read nothing it may not and decode the same (buffer sizes = k*4096 and k*4096 + 2:
+    last pass misaligned by 2 and by 0)."""
+    nbits, delay = 4 * 1020, 200
+    size = 3 * 4096 + tail
+    syms, _ = orc.gen_coded_stream(9420 + tail, nbits, 3.0, 24.0, 5)
+    d = pkg.Viterbi224(delay + 2 * 1020)
+    d.init(0)
+    want = d.stream_decode(syms, delay)
+    buf = pkg.DeviceBuffer(size)
+    off = size - 2 * nbits
+    host = np.zeros(size, np.uint8)
+    host[off:] = syms
+    assert pkg.v224_lib().v224hip_h2d(buf.ptr, host.ctypes.data, size) == 0
+    dout = pkg.DeviceBuffer(nbits)
+    d.init(0)
+    d.stream_decode_dev(buf, nbits, delay, dout, sym_offset=off)
+    d.sync()
+    assert np.array_equal(dout.to_numpy(np.uint8), want)
+    d.init(0)
+    d.update_dev(buf, nbits, byte_offset=off)
+    o = orc.OracleV224(delay + 2 * 1020, orc.FAST)
+    o.init(0)
+    o.update(syms, nbits)
+    assert d.chainback(1000, 0).tobytes() == o.chainback(1000, 0).tobytes()
+    o.close()
+    d.close()

@@ -98,3 +98,18 @@ def test_spread_bound():
         worst = max(worst, o.spread())
     assert worst < 1000 + 23 * 510
     o.close()
+
+
+def test_oracle_decodeword_matches_sse2_reference_on_clean_streams():
+    """decodeword exists only in viterbi224_sse2.c (:206-243).  On a clean coded stream the SSE2 and the
+    port decoder keep the same survivor, so the oracle's restatement (port decisions) must return the reference's
+    words: every query of tests/golden/decodeword_sse2.npz, incl. best-state search and ring wrap."""
+    z = np.load(os.path.join(orc.GOLDEN, "decodeword_sse2.npz"))
+    for name in [str(n) for n in z["names"]]:
+        nbits, length = int(z[name + "/nbits"]), int(z[name + "/length"])
+        o = orc.OracleV224(length, orc.FAST)
+        o.init(0)
+        o.update(z[name + "/syms"], nbits)
+        got = [o.decodeword(int(d), int(e)) for d, e in z[name + "/queries"]]
+        assert got == [int(w) for w in z[name + "/sse2_words"]], name
+        o.close()

@@ -55,3 +55,32 @@ def test_oracle_vdecode_restatement(name):
     delay = int(args[args.index("-d") + 1]) if "-d" in args else 200
     out, st = orc.vdecode(z[name + "/syms"], delay, int("-p" in args), "-F" in args)
     assert out == z[name + "/stdout"].tobytes()
+
+
+E = os.path.join(orc.GOLDEN, "vdecode_stderr.npz")
+
+
+def status_lines(stderr_bytes):
+    """stderr of a vdecode run without the program name (argv[0] differs) and without this harness's own RESULT line"""
+    out = []
+    for ln in stderr_bytes.decode().splitlines():
+        if ln.startswith("RESULT ") or not ln.strip():
+            continue
+        out.append(ln.split(": ", 1)[1] if ": " in ln else ln)
+    return out
+
+
+@pytest.mark.parametrize("whole", ["0", "1"], ids=["blockwise", "whole_input"])
+@pytest.mark.parametrize("name", [str(n) for n in np.load(E)["names"]])
+def test_reencode_symbol_error_statistic_matches_reference_stderr(harness, name, whole):
+    """vdecode.c:159-184: the decoded bits are re-encoded and compared with the hard-sliced received symbols; the tally
+    goes to stderr every -i bits.  Fixture = stderr of the reference's own vdecode (port decoder) with -i 256, in the C
+    locale: every status line, the `flipping phase` notice and the delay warning, in the same order."""
+    z = np.load(E)
+    args = [str(a) for a in z[name + "/args"]]
+    p = subprocess.run([harness] + args, input=np.load(G)[name + "/syms"].tobytes(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, check=True, timeout=600,
+                       env=dict(os.environ, VDECODE_WHOLE=whole, LANG="C", LC_ALL="C"))
+    want = status_lines(z[name + "/stderr"].tobytes())
+    assert any("symerrs" in ln for ln in want)
+    assert status_lines(p.stderr) == want
