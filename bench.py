@@ -139,7 +139,8 @@ def chain_workload(a, rank, world, local, dist, torch, pkg, redev="cuda"):
                 merged.update(d)
             bps = 1024.545058 / 2
             ovl = [int((plan[i + 1][1] - plan[i + 1][0]) * N / fs * bps) for i in range(len(plan) - 1)]
-            bits_all, ok, tot = segmod.stitch([merged[g] for g in range(len(plan))], ovl)
+            bits_all, ok, tot = segmod.stitch([merged[g] for g in range(len(plan))], ovl,
+                                              from_start=[plan[i + 1][0] == 0 for i in range(len(plan) - 1)])
             out["bits"] = bits_all
             seams = {"matched": ok, "total": tot}
         else:

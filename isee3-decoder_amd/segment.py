@@ -22,7 +22,7 @@ def plan_segments(nblocks, nseg, warm_blocks):
     return [(max(0, edges[i] - warm_blocks), edges[i], edges[i + 1]) for i in range(nseg) if edges[i + 1] > edges[i]]
 
 
-def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=400, settled=2300):
+def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=400, settled=2300, from_start=None):
     """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments;
     overlap_bits[i]: how many decoded bits lie between the start of part i+1 and the cut (its warm-up region).
     A probe is taken from the settled end of that region and located in the previous part -- but only where it
@@ -31,11 +31,21 @@ def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=4
     occur exactly ONCE in that range (repetitive telemetry can match one frame off), and with that alignment the two
     parts must agree on EVERYTHING they share from up to `verify_back` bits before the probe (not before the part's
     `settled` bit) to the end of part i; otherwise the seam counts as unmatched.
+    from_start[i] (optional): part i+1 begins at the very first sample of the capture (its warm-up was clipped there), so
+    it decodes the same samples as the parts before it from bit 0 on: everything joined so far must be a prefix of it.
     Returns (joined bits, seams matched, seams total)."""
     out = parts[0]
     ok = 0
-    for nxt, ovl in zip(parts[1:], overlap_bits):
+    for i, (nxt, ovl) in enumerate(zip(parts[1:], overlap_bits)):
         placed = False
+        if from_start is not None and from_start[i]:
+            if len(nxt) >= len(out) and nxt.startswith(out):
+                out, placed = nxt, True
+            if placed:
+                ok += 1
+            else:
+                out = out + nxt
+            continue
         # the first ~2300 bits of a restarted decode are unreliable: start-up delay, and vdecode decides its
         # symbol-pair phase only once per 2048 ODD symbols = two frames (vdecode.c:122-139).  Probe between
         # there and the end of the overlap.
@@ -99,6 +109,6 @@ def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=7, conc
         raise errors[0]
     bps = (1024.545058 / 2 if symrate in (None, "1024") else float(symrate) / 2)
     overlaps = [int((plan[i + 1][1] - plan[i + 1][0]) * N / samprate * bps) for i in range(len(plan) - 1)]
-    bits, ok, seams = stitch(parts, overlaps)
+    bits, ok, seams = stitch(parts, overlaps, from_start=[plan[i + 1][0] == 0 for i in range(len(plan) - 1)])
     processed = sum((b1 - b0) * N for b0, _, b1 in plan)
     return bits, ok, seams, processed

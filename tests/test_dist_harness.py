@@ -65,6 +65,11 @@ def test_stitch_locates_the_seam_by_position_and_verifies_it():
         bad[i] ^= 1
     out, ok, tot = segment.stitch([p0, bytes(bad)], [ovl])
     assert ok == 0 and len(out) == len(p0) + len(bad)
+    # segments whose warm-up was clipped at the start of the capture decode the same samples from bit 0
+    out, ok, tot = segment.stitch([full[:300], full[:900], full[:1500]], [512, 1024], from_start=[True, True])
+    assert (ok, tot) == (2, 2) and out == full[:1500]
+    out, ok, tot = segment.stitch([full[:300], full[1:900]], [512], from_start=[True])
+    assert ok == 0
     # periodic frames: alignment is decided by position, never a frame off
     frame = bytes(rng.integers(48, 50, 1024, dtype=np.uint8))
     per = frame * 24
