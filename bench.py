@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: K=24 r=1/2 Viterbi streaming decode on MI355X.
+"""bench.py -- headline benchmark of the ISEE-3 receive-chain hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): one 1e7-symbol synthetic soft-symbol stream per GPU, decoded
-with the semantics of `vdecode -d 200` (one trellis step + decodebit(200,0) per bit), inputs
-resident in HBM before the timed region, decoded bits left in HBM.  A "step" = one full pass of
-that stream (init + 5e6 trellis steps + 5e6 tracebacks).  N>1: every rank decodes its own
-independent stream (segments shard one-per-GPU, no collective in the data path) -> weak scaling.
+BASELINE.json's metric has two halves; the ONE JSON line rank 0 prints carries both:
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      : HBM roofline of the ACS kernel (algorithmic 34 603 008 B per trellis step),
-                  average launch time from HIP events recorded on the decoder's own stream
-  cpu_baseline  : the reference's SSE2 decoder (oracle/_ref, built from /root/reference in the
-                  build container) on ONE host core, bounded sample
+  top level  "Viterbi K=24 Msymbols/s" on BASELINE configs[1]: one 1e7-symbol synthetic soft-symbol stream per GPU,
+             decoded with the semantics of `vdecode -d 200` (one trellis step + decodebit(200,0) per bit).  A "step" =
+             one full pass of that stream (init + 5e6 trellis steps + 5e6 tracebacks).  Symbols are resident in HBM
+             before the timed region starts and the decoded bits stay there (the 10 MB H2D / 5 MB D2H, ~1 ms of a
+             ~4 s step, are excluded -- stated in config.residency).
+  "chain"    "end-to-end IQ Msamples/s" on BASELINE configs[2]: 60 s x 250 kS/s synthetic int16 IQ per GPU through
+             pmdemod | symdemod | vdecode in one process (libisee3chain.so), capture resident in HBM
+             (isee3_chain_run_dev); the rate with the capture in host memory (PCIe included) rides along.
+
+N > 1 (torch.distributed.run, one rank per GPU, RCCL only for the barrier / MAX / SUM): every rank works on its own
+independent stream and capture -- segments shard one per GPU, no collective in the data path -> weak scaling.
+
+  roofline      the dominant kernel k_acs_lds15.  It is VALU-issue bound (15 trellis steps share ONE pass over the
+                path metrics), so `frac` = VALU issue time / launch time <= 1; `hbm_physical_frac` = PMC bytes / launch
+                time / 8 TB/s; the SURVEY 8(d) algorithmic figure (34 603 008 B per trellis step) is kept as
+                `algorithmic_x_peak`.  Launch time: HIP events on the decoder's own stream, live in this run.
+  cpu_baseline  the reference's SSE2 decoder (oracle/_ref, built from /root/reference in the build container) on ONE
+                host core, bounded sample; chain.cpu_baseline: oracle pmdemod -> reference symdemod -> reference
+                vdecode (SSE2) on the first seconds of the same capture.
 """
 import argparse
 import importlib.util
@@ -25,6 +35,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 ALG_BYTES_PER_STEP = (1 << 23) * 2 * 2 + (1 << 23) // 8          # read + write u16 metrics + decisions
 HBM_PEAK_GBS = 8000.0
+CLOCK_GHZ = 2.4                                                 # MI355X max shader clock (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4
+WAVES_PER_LAUNCH = 256 * 16                                     # k_acs_lds15: 256 workgroups x 1024 threads
 
 
 def load_pkg():
@@ -40,11 +53,15 @@ def load_pkg():
     return mod
 
 
-def cpu_baseline(nbits_sample):
-    """Reference SSE2 decoder on one host core (falls back to the oracle port restatement)."""
+def _orc():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    syms = np.full(2 * nbits_sample, 128, np.uint8)
+    return orc
+
+
+def cpu_baseline(nbits_sample):
+    """Reference SSE2 decoder on one host core (falls back to the oracle port restatement)."""
+    orc = _orc()
     rng = np.random.default_rng(1)
     syms = rng.integers(0, 256, 2 * nbits_sample, dtype=np.uint8)
     if orc.have_ref():
@@ -80,90 +97,160 @@ def cpu_baseline(nbits_sample):
     return res
 
 
-def chain_workload(a, rank, world, local, dist, torch, pkg, redev="cuda"):
-    """BASELINE.json configs[2]/[3]: full pmdemod | symdemod | vdecode chain on synthetic int16 IQ,
-    one independent capture per GPU (libisee3chain.so = the three C pipe stages as threads of the
-    calling process; the capture is fed from host memory through a pipe, so PCIe and pipe copies are
-    inside the time)."""
-    from importlib import import_module
-    synth = import_module("isee3_decoder_amd.synth")
-    harness = import_module("isee3_decoder_amd.harness")
-    fs = float(a.chain_rate)
-    # segmented mode: ONE capture, the same on every rank; otherwise one capture per rank
-    iq, sent = synth.iq_capture(3 if a.chain_segments > 1 else 3 + rank, fs, a.chain_seconds, amp=None)
-    pkg.v224_lib().v224hip_set_device(local)
-    pkg.dsp_lib().isee3dsp_set_device(local)
-    out = {}
-    segmod = import_module("isee3_decoder_amd.segment")
-    N = 1 << int(np.rint(np.log2(fs / a.chain_bin)))
-    nblocks = (len(iq) // 2) // N
-    plan = segmod.plan_segments(nblocks, a.chain_segments, a.chain_warm_blocks) if a.chain_segments > 1 else None
-    # configs[4]: the capture is cut into overlapped block-aligned segments, segment g -> rank g mod world,
-    # two chains at a time per GPU (their kernels overlap), parts stitched on rank 0
-    mine = harness.shard_segments(len(plan), world, rank) if plan is not None else []
+def chain_cpu_baseline(iq, fs, binsize, seconds):
+    """The reference chain on ONE host core over the first `seconds` of the capture: pmdemod = the oracle restatement
+    (pmdemod.c needs FFTW3, absent: not buildable), symdemod and vdecode (SSE2 decoder) = the reference's own binaries
+    where oracle/_ref travelled along, else their oracle restatements."""
+    orc = _orc()
+    os.environ["OMP_NUM_THREADS"] = "1"
+    N = 1 << int(np.rint(np.log2(fs / binsize)))
+    nsamp = int(seconds * fs) // N * N
+    part = np.ascontiguousarray(iq[:2 * nsamp])
+    t0 = time.perf_counter()
+    bb, _, _, _ = orc.pmdemod(part, samprate=fs, binsize=binsize, want_pre=False)
+    t1 = time.perf_counter()
+    if orc.have_ref():
+        sy = orc.ref_cli("symdemod_ref", ["-q", "-r", str(int(fs)), "-c", "1024"], bb.tobytes())
+        t2 = time.perf_counter()
+        bits = orc.ref_cli("vdecode_sse2_ref", ["-q"], sy)
+        kind = "reference"
+        what = "oracle pmdemod (pmdemod.c unbuildable: FFTW3) | reference symdemod.c | reference vdecode.c + viterbi224_sse2.c"
+    else:
+        sy, _, _ = orc.symdemod(bb, samprate=int(fs), c_opt="1024")
+        sy = sy.tobytes()
+        t2 = time.perf_counter()
+        bits, _ = orc.vdecode(np.frombuffer(sy, np.uint8))
+        kind, what = "port", "oracle pmdemod | oracle symdemod | oracle vdecode (port semantics, 1 thread)"
+    t3 = time.perf_counter()
+    return {"value": round(nsamp / (t3 - t0) / 1e6, 6), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": "first %.1f s of the capture (%d samples), %s: pmdemod %.2f s, symdemod %.2f s, vdecode %.2f s, %d bits"
+                      % (nsamp / fs, nsamp, what, t1 - t0, t2 - t1, t3 - t2, len(bits))}
 
-    def step():
-        # libisee3chain.so: the three C pipe stages as threads of THIS process (HIP context stays warm)
-        if plan is None:
-            out["bits"] = pkg.run_chain(iq, samprate=fs, binsize=a.chain_bin, symrate="1024", decode_delay=a.delay)
-            return
-        import threading
-        todo, parts, lock = list(mine), {}, threading.Lock()
 
-        def worker():
-            while True:
-                with lock:
-                    if not todo:
-                        return
-                    g = todo.pop(0)
-                b0, _, b1 = plan[g]
-                parts[g] = pkg.run_chain(iq[2 * b0 * N:2 * b1 * N], samprate=fs, binsize=a.chain_bin, symrate="1024",
-                                         decode_delay=a.delay)
-        ts = [threading.Thread(target=worker) for _ in range(2)]
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        out["parts"] = parts
+def pmc_constants(kern):
+    """PMC passes cannot share a run with the timing: the per-launch HBM bytes and VALU instruction count of the kernel
+    are committed constants (profiles/), refreshed whenever the kernel changes."""
+    for tname in ("r02_pmc_lds15.json", "r01c_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == kern:
+                return tj, "profiles/" + tname
+    return {}, None
 
-    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
-    dt = harness.timed_steps(step, a.steps, a.warmup, fence)
-    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, redev)
-    seams = None
-    if plan is not None:
-        allparts = [out["parts"]]
-        if world > 1:
-            allparts = [None] * world
-            dist.all_gather_object(allparts, out["parts"])
-        if rank == 0:
-            merged = {}
-            for d in allparts:
-                merged.update(d)
-            bps = 1024.545058 / 2
-            ovl = [int((plan[i + 1][1] - plan[i + 1][0]) * N / fs * bps) for i in range(len(plan) - 1)]
-            bits_all, ok, tot = segmod.stitch([merged[g] for g in range(len(plan))], ovl,
-                                              from_start=[plan[i + 1][0] == 0 for i in range(len(plan) - 1)])
-            out["bits"] = bits_all
-            seams = {"matched": ok, "total": tot}
-        else:
-            out["bits"] = b""
-    got = np.frombuffer(out["bits"], np.uint8) - ord("0")
+
+def chain_check(bits, sent):
+    got = np.frombuffer(bits, np.uint8) - ord("0")
     s = "".join(map(str, sent))
     # the tail: vdecode may need one 2048-symbol frame to settle its symbol-pair phase (vdecode.c:126-139)
-    ok = len(got) > 2500 and "".join(map(str, got[-1100:-100])) in s
+    return len(got), bool(len(got) > 2500 and "".join(map(str, got[-1100:-100])) in s)
+
+
+def chain_record(a, ctx, seconds, rate, binsize, steps, warmup, with_cpu):
+    """BASELINE configs[2] / [3]: the whole chain on one independent capture per rank.  Timed with the capture resident
+    in HBM (the contract's `value`) and again with the capture in host memory (PCIe inclusive)."""
+    pkg, harness, synth, dist, torch = ctx["pkg"], ctx["harness"], ctx["synth"], ctx["dist"], ctx["torch"]
+    rank, world, redev = ctx["rank"], ctx["world"], ctx["redev"]
+    fs = float(rate)
+    iq, sent = synth.iq_capture(3 + rank, fs, seconds, amp=None)
+    d_iq = pkg.DeviceBuffer.from_numpy(iq)
+    out, ms = {}, []
+
+    def step_dev():
+        out["bits"] = pkg.run_chain(d_iq, samprate=fs, binsize=binsize, symrate="1024", decode_delay=a.delay, stage_ms=ms)
+
+    def step_host():
+        out["hbits"] = pkg.run_chain(iq, samprate=fs, binsize=binsize, symrate="1024", decode_delay=a.delay)
+
+    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
+    dt_local = harness.timed_steps(step_dev, steps, warmup, fence)
+    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt_local, redev)
+    hsteps = max(1, min(steps, 3))
+    dth = harness.max_over_ranks(dist if world > 1 else None, torch, harness.timed_steps(step_host, hsteps, 1, fence), redev)
+    per_rank = harness.gather_per_rank(dist if world > 1 else None, round(dt_local / steps * 1e3, 3))
+    nbits, ok = chain_check(out["bits"], sent)
+    d_iq.free()
+    if rank != 0:
+        return None
+    nsamp = len(iq) // 2
+    rec = {"metric": "end-to-end IQ Msamples/s", "value": round(nsamp * world * steps / dt / 1e6, 3), "unit": "Msamples/s",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_per_rank": per_rank,
+           "workload": "pmdemod|symdemod|vdecode in one process on %g s of %g kS/s int16 IQ, %g Hz bins (N = 2^%d), 1024 sym/s "
+                       "Manchester, vdecode -d %d, one independent capture per GPU; capture resident in HBM, sample streams "
+                       "between the stages stay in HBM" % (seconds, fs / 1e3, binsize, int(np.rint(np.log2(fs / binsize))), a.delay),
+           "decoded_bits": nbits,
+           "host_capture": {"value": round(nsamp * world * hsteps / dth / 1e6, 3), "ms_per_step": round(dth / hsteps * 1e3, 3),
+                            "what": "the same with the capture in pageable host memory (isee3_chain_run_mem): PCIe H2D of 4 B "
+                                    "per sample inside the time", "identical_output": bool(out["hbits"] == out["bits"])},
+           "stage_engine_ms": {"pmdemod": round(ms[0], 3), "symdemod": round(ms[1], 3), "vdecode": round(ms[2], 3),
+                               "what": "ms the last timed step spent inside the engine calls of each stage (they include "
+                                       "waiting for the GPU; the three stages run concurrently)"},
+           "algorithmic_bytes_per_sample": {"pmdemod": 6, "symdemod": 2,
+                                            "viterbi": round(1024.545058 / fs * 17301504, 1)},
+           "check": {"decoded_run_found_in_sent_stream": ok}}
+    if with_cpu:
+        rec["cpu_baseline"] = chain_cpu_baseline(iq, fs, binsize, a.chain_cpu_seconds)
+        rec["speedup_vs_cpu_1core"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
+    return rec
+
+
+def chain_workload(a, ctx):
+    """`--workload chain`: the chain line alone (profiling), or -- with --chain-segments S > 1 -- BASELINE configs[4]:
+    ONE capture cut into S overlapped block-aligned segments, segment g -> rank g mod world, two chains at a time per
+    GPU, parts stitched on rank 0 (strong scaling)."""
+    pkg, harness, synth, dist, torch = ctx["pkg"], ctx["harness"], ctx["synth"], ctx["dist"], ctx["torch"]
+    rank, world, redev = ctx["rank"], ctx["world"], ctx["redev"]
+    if a.chain_segments <= 1:
+        rec = chain_record(a, ctx, a.chain_seconds, a.chain_rate, a.chain_bin, a.steps, a.warmup, not a.no_cpu and world == 1)
+        if rank == 0:
+            rec.update({"n_gpus": world, "ranks_seen": ctx["ranks_seen"], "higher_is_better": True, "scaling": "weak",
+                        "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic", "config": {"workload": rec.pop("workload")},
+                        "roofline": None})
+            print(json.dumps(rec), flush=True)
+        return
+    from importlib import import_module
+    segmod = import_module("isee3_decoder_amd.segment")
+    fs = float(a.chain_rate)
+    iq, sent = synth.iq_capture(3, fs, a.chain_seconds, amp=None)        # the same capture on every rank
+    N = 1 << int(np.rint(np.log2(fs / a.chain_bin)))
+    nblocks = (len(iq) // 2) // N
+    plan = segmod.plan_segments(nblocks, a.chain_segments, a.chain_warm_blocks)
+    mine = harness.shard_segments(len(plan), world, rank)
+    d_iq = pkg.DeviceBuffer.from_numpy(iq)
+    out = {}
+
+    def run_one(b0, b1):
+        view = pkg.DeviceBuffer.__new__(pkg.DeviceBuffer)            # a window into the resident capture
+        view.ptr, view.nbytes = d_iq.ptr + 4 * b0 * N, 4 * (b1 - b0) * N
+        try:
+            return pkg.run_chain(view, samprate=fs, binsize=a.chain_bin, symrate="1024", decode_delay=a.delay)
+        finally:
+            view.ptr = None
+
+    def step():
+        out["parts"] = harness.run_segments(plan, mine, run_one, concurrency=2)
+
+    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
+    dt_local = harness.timed_steps(step, a.steps, a.warmup, fence)
+    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt_local, redev)
+    per_rank = harness.gather_per_rank(dist if world > 1 else None, round(dt_local / a.steps * 1e3, 3))
+    bits, seams = harness.gather_and_stitch(dist if world > 1 else None, plan, out["parts"], N / fs * 1024.545058 / 2,
+                                            segmod.stitch)
     if rank == 0:
+        nbits, ok = chain_check(bits, sent)
         nsamp = len(iq) // 2
-        units = nsamp * a.steps if plan is not None else nsamp * world * a.steps   # segmented: ONE capture in total
         print(json.dumps({
-            "metric": "end-to-end IQ Msamples/s", "value": round(units / dt / 1e6, 3),
-            "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong" if plan is not None else "weak",
-            "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic",
-            "config": {"workload": "pmdemod|symdemod|vdecode on %g s of %g kS/s int16 IQ, %g Hz bins, 1024 sym/s "
-                                   "Manchester, one capture per GPU, capture in host memory (H2D / D2H of every stage included)"
-                                   % (a.chain_seconds, fs / 1e3, a.chain_bin), "decoded_bits": int(len(got)),
-                       "segments": a.chain_segments, "warm_blocks": a.chain_warm_blocks if plan is not None else 0,
-                       "seams": seams},
-            "roofline": None, "check": {"decoded_run_found_in_sent_stream": bool(ok)}}), flush=True)
+            "metric": "end-to-end IQ Msamples/s", "value": round(nsamp * a.steps / dt / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": world, "ranks_seen": ctx["ranks_seen"], "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_per_rank": per_rank, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic",
+            "config": {"workload": "ONE capture of %g s of %g kS/s int16 IQ (%g Hz bins) cut into %d overlapped block-aligned "
+                                   "segments (%d after merging those that start at block 0), warm-up %d blocks, segment g -> "
+                                   "rank g mod %d, two chains at a time per GPU, capture resident in HBM, stitched on rank 0"
+                                   % (a.chain_seconds, fs / 1e3, a.chain_bin, a.chain_segments, len(plan), a.chain_warm_blocks, world),
+                       "decoded_bits": nbits, "segments": len(plan), "seams": seams,
+                       "samples_processed_incl_overlap": int(sum((b1 - b0) * N for b0, _, b1 in plan))},
+            "roofline": None, "check": {"decoded_run_found_in_sent_stream": ok}}), flush=True)
 
 
 def main():
@@ -186,10 +273,13 @@ def main():
     ap.add_argument("--split-warm", type=int, default=14280, help="warm-up bits before each part (14 chunks)")
     ap.add_argument("--cpu-bits", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="skip the chain half of the metric (kernel profiling runs)")
     ap.add_argument("--workload", choices=["viterbi", "chain"], default="viterbi")
     ap.add_argument("--chain-seconds", type=float, default=60.0)
     ap.add_argument("--chain-rate", type=float, default=250000.0)
     ap.add_argument("--chain-bin", type=float, default=1.0)
+    ap.add_argument("--chain-steps", type=int, default=0, help="timed chain steps in the default run (0: as --steps)")
+    ap.add_argument("--chain-cpu-seconds", type=float, default=6.0, help="seconds of capture given to the CPU chain baseline")
     ap.add_argument("--chain-segments", type=int, default=1,
                     help="> 1: cut ONE capture into this many overlapped segments over all ranks (configs[4])")
     ap.add_argument("--chain-warm-blocks", type=int, default=7)
@@ -217,16 +307,19 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     pkg = load_pkg()
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+    harness = import_module("isee3_decoder_amd.harness")
+    pkg.v224_lib().v224hip_set_device(local)
+    pkg.dsp_lib().isee3dsp_set_device(local)
+    ctx = dict(pkg=pkg, harness=harness, synth=synth, dist=dist, torch=torch, rank=rank, world=world, redev=redev)
+    ctx["ranks_seen"] = harness.ranks_seen(dist if world > 1 else None, torch, redev)
     if a.workload == "chain":
-        chain_workload(a, rank, world, local, dist, torch, pkg, redev)
+        chain_workload(a, ctx)
         if world > 1:
             dist.destroy_process_group()
         return
-    pkg.v224_lib().v224hip_set_device(local)
-    from importlib import import_module
-    synth = import_module("isee3_decoder_amd.synth")
 
-    harness = import_module("isee3_decoder_amd.harness")
     nbits = a.symbols // 2
     nseg = world * a.segments_per_gpu
     mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
@@ -263,7 +356,8 @@ def main():
         for sg in segs:
             redone[0] += pkg.stream_decode_split(sg["decs"], sg["d_syms"], nbits, a.delay, sg["d_out"], a.split_warm)
 
-    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
+    dd = dist if world > 1 else None
+    fence = harness.make_fence(dd, torch.cuda.synchronize)
     single = None
     if a.split > 1:
         # reference pass: ONE decoder per stream (1 warm-up + 1 timed step); its kernel timing feeds `roofline`, its
@@ -274,13 +368,13 @@ def main():
         dt1 = harness.timed_steps(step_single, 1, 0, fence)
         launches, ms, steps_timed = dec.acs_stats()
         dec.set_option("profile", 0)
-        dt1 = harness.max_over_ranks(dist if world > 1 else None, torch, dt1, redev)
+        dt1 = harness.max_over_ranks(dd, torch, dt1, redev)
         single_out = segs[0]["d_out"].to_numpy(np.uint8).copy()
         harness.timed_steps(step_split, 0, a.warmup, fence)
         redone[0] = 0
         dec.set_option("profile", 4)
         dec.acs_stats(reset=True)
-        dt = harness.timed_steps(step_split, a.steps, 0, fence)
+        dt_local = harness.timed_steps(step_split, a.steps, 0, fence)
         l2, ms2, st2 = dec.acs_stats()
         dec.set_option("profile", 0)
         single = {"value": round(2 * nbits * nseg / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 3),
@@ -290,10 +384,11 @@ def main():
         harness.timed_steps(step_single, 0, a.warmup, fence)
         dec.set_option("profile", 4)
         dec.acs_stats(reset=True)
-        dt = harness.timed_steps(step_single, a.steps, 0, fence)
+        dt_local = harness.timed_steps(step_single, a.steps, 0, fence)
         launches, ms, steps_timed = dec.acs_stats()
         dec.set_option("profile", 0)
-    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt, redev)
+    dt = harness.max_over_ranks(dd, torch, dt_local, redev)
+    per_rank = harness.gather_per_rank(dd, round(dt_local / a.steps * 1e3, 3))
     d_out, bits, noise_mask = segs[0]["d_out"], segs[0]["bits"], segs[0]["noise_mask"]
 
     # sanity: decoded bits equal sent bits away from the noise blocks (does not replace tests/)
@@ -305,31 +400,65 @@ def main():
     for i in nz[:: 256]:
         lo = max(0, i - 1200); clean[lo:i + 1200] = False
     ber = float(np.mean(dec_bits[clean] != ref_bits[clean])) if clean.any() else -1.0
+    for sg in segs:                                     # free the decoders (2.2 GiB rings) before the chain runs
+        for d in sg["decs"]:
+            d.close()
+        sg["d_syms"].free(); sg["d_out"].free()
+
+    chain = None
+    if not a.no_chain:
+        chain = chain_record(a, ctx, a.chain_seconds, a.chain_rate, a.chain_bin, a.chain_steps or a.steps, max(1, a.warmup),
+                             world == 1 and not a.no_cpu)
+        pkg.release_chain_objects()
 
     if rank == 0:
         total_syms = 2 * nbits * nseg * a.steps
         avg_ms = ms / launches if launches else float("nan")
         steps_per_launch = steps_timed / launches if launches else 0
-        ach = ALG_BYTES_PER_STEP * steps_per_launch / (avg_ms * 1e-3) / 1e9 if launches else None
-        traffic = None
         kern = {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8", 3: "k_acs_lds15"}[eng]
-        tsrc = None
-        for tname in ("r01c_pmc_traffic.json", "r01_pmc_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == kern:   # PMC passes cannot share a run with the timing: committed constant
-                    traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + tname
-                    break
+        pmc, psrc = pmc_constants(kern)
+        traffic = pmc.get("hbm_bytes_per_launch")
+        valu = pmc.get("valu_insts_per_wave")
+        cyc = pmc.get("valu_cycles_per_inst", 4.2)
+        alg = ALG_BYTES_PER_STEP * steps_per_launch
+        roof = {"kernel": kern, "bound": "valu-issue" if valu else "hbm",
+                "avg_launch_ms": round(avg_ms, 6), "launches_timed": launches, "trellis_steps_per_launch": steps_per_launch,
+                "measured_on": "the single-decoder reference pass of this run (one %s at a time on the GPU; HIP events on the "
+                               "decoder's own stream around runs of back-to-back launches)" % kern if a.split > 1 else "the timed steps",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % psrc,
+                "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "algorithmic_bytes_per_launch": int(alg)}
+        if launches:
+            t = avg_ms * 1e-3
+            roof["algorithmic_GBps"] = round(alg / t / 1e9, 1)
+            roof["algorithmic_x_peak"] = round(alg / t / 1e9 / HBM_PEAK_GBS, 4)
+            if traffic:
+                roof["hbm_physical_GBps"] = round(traffic / t / 1e9, 1)
+                roof["hbm_physical_frac"] = round(traffic / t / 1e9 / HBM_PEAK_GBS, 4)
+            if valu:
+                # wave-level VALU instructions per second, chip-wide, against what 1024 SIMDs can issue for this mix
+                ach = valu * WAVES_PER_LAUNCH / t / 1e9
+                peak = N_SIMD * CLOCK_GHZ / cyc
+                roof.update({"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s (VALU)",
+                             "frac": round(ach / peak, 4), "valu_insts_per_wave": valu, "valu_cycles_per_inst": cyc,
+                             "note": "15 trellis steps share one pass over the path metrics, so the launch is bound by VALU issue, "
+                                     "not by HBM: frac = VALU instructions per wave x 4 waves per SIMD x %.1f cycles per instruction "
+                                     "(measured for this VOP3P / VOP2 mix, profiles/r01_valu_rate.txt) / (launch time x %.1f GHz); "
+                                     "the SURVEY 8(d) algorithmic bytes exceed what is physically moved (algorithmic_x_peak)"
+                                     % (cyc, CLOCK_GHZ)})
+            elif traffic:
+                roof.update({"achieved": roof["hbm_physical_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": roof["hbm_physical_frac"]})
         res = {
             "metric": "Viterbi K=24 Msymbols/s",
             "value": round(total_syms / dt / 1e6, 4), "unit": "Msymbols/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "n_gpus": world, "ranks_seen": ctx["ranks_seen"], "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_per_rank": per_rank,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "viterbi224 ACS+chainback streaming, 2^23 states, 8-bit soft syms, "
                                    "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
+                       "residency": "symbols in HBM before the timed region, decoded bits left in HBM (excluded: %.1f MB H2D + "
+                                    "%.1f MB D2H per step, ~1 ms of PCIe)" % (2 * nbits / 1e6, nbits / 1e6),
                        "engine": {0: "simple", 1: "fused", 2: "lds8", 3: "lds15"}[eng],
                        "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8, 3: 15}[eng],
                        "chunk_bits": chunk,
@@ -341,28 +470,15 @@ def main():
                                    "decoder's at the seam (all 2^23 states equal => identical continuation, else the part is "
                                    "decoded again): v224hip_stream_decode_split" % (a.split, a.split, a.split_warm),
                            "parts_redone": redone[0], "single_decoder": single}},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tsrc,
-                         "physical_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and launches) else None,
-                         "note": "algorithmic bytes (SURVEY 8d: 34 603 008 B per trellis step) exceed the physical traffic "
-                                 "because one launch carries the metrics through several steps; the launch itself is "
-                                 "VALU-issue bound, see DESIGN.md section 3",
-                         "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_STEP * steps_per_launch),
-                         "kernel": kern,
-                         "measured_on": "the single-decoder reference pass of this run (one k_acs_lds15 at a time on the GPU); in "
-                                        "the split pass two decoders' launches overlap" if a.split > 1 else "the timed steps",
-                         "avg_launch_ms": round(avg_ms, 6), "trellis_steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "launches_timed": launches},
+            "roofline": roof,
             "check": {"ber_clean": ber, "bits": int(clean.sum())},
         }
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(a.cpu_bits)
             res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        if chain is not None:
+            res["chain"] = chain
         print(json.dumps(res), flush=True)
-    for sg in segs:
-        for d in sg["decs"]:
-            d.close()
     if world > 1:
         dist.destroy_process_group()
 

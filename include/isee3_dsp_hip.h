@@ -22,6 +22,12 @@ extern "C" {
 const char *isee3dsp_last_error(void);
 int isee3dsp_set_device(int dev);
 
+/* device / pinned host memory for C callers that keep streams resident in HBM (used by libisee3chain.so) */
+void *isee3dsp_dev_alloc(size_t bytes);
+void  isee3dsp_dev_free(void *d);
+int   isee3dsp_h2d(void *d_dst, const void *h_src, size_t bytes);
+int   isee3dsp_d2h(void *h_dst, const void *d_src, size_t bytes);
+
 /* ------------------------------------------------------------------ symdemod (symdemod.c) ---- */
 /* One handle owns: a device copy of the current sample window and its exact int64 prefix sum. */
 void *symd_create(int max_samples);
@@ -31,6 +37,20 @@ void  symd_destroy(void *h);
  * P[k] = sum(samples[0..k)) in int64.  Every integrate-and-dump sum of symdemod.c:227-235 /
  * :283-293 is then a difference of two P entries -- identical integers. */
 int symd_load(void *h, const int16_t *samples, int n, int is_dev);
+
+/* The same in pieces, for a window buffer that LIVES in device memory (symdemod.c:96-125: a two-window buffer that is
+ * slid with memmove and topped up by read()).  The handle's buffer holds max_samples samples, zero after create /
+ * symd_store_reset:
+ *   symd_store_slide(h, slide, nsamples)  == memmove(buf, buf + slide, (nsamples - slide) samples); the rest of the
+ *                                            buffer keeps its old contents, exactly like the reference's
+ *   symd_store_put(h, at, src, n, dev)    == copy n samples to buf[at..at+n) from host or device memory (with a device
+ *                                            source the call returns when the copy is done: src may be recycled)
+ *   symd_store_scan(h, n)                 == prefix sums over buf[0..n), after which timesearch / demod work on it
+ * symd_load(h, s, n, dev) = symd_store_put(h, 0, s, n, dev) + symd_store_scan(h, n). */
+int symd_store_reset(void *h);
+int symd_store_slide(void *h, int slide, int nsamples);
+int symd_store_put(void *h, int at, const int16_t *src, int n, int src_is_dev);
+int symd_store_scan(void *h, int n);
 
 /* timesearch (symdemod.c:260-335) for offsets t = 0..noff-1 counted from base sample `lo`:
  *   sw[0] = 0, sw[k+1] = reference switchpoints[k]  (2*symbolclocks*nsymbols + 1 entries, host)

@@ -247,8 +247,9 @@ class Viterbi224:
 # libisee3dsp_hip.so : pmdemod / symdemod kernels (include/isee3_dsp_hip.h)
 # ------------------------------------------------------------------------------------------------
 DSP_SYMBOLS = [
-    "isee3dsp_last_error", "isee3dsp_set_device",
+    "isee3dsp_last_error", "isee3dsp_set_device", "isee3dsp_dev_alloc", "isee3dsp_dev_free", "isee3dsp_h2d", "isee3dsp_d2h",
     "symd_create", "symd_destroy", "symd_load", "symd_timesearch", "symd_demod",
+    "symd_store_reset", "symd_store_slide", "symd_store_put", "symd_store_scan",
     "pmd_create", "pmd_destroy", "pmd_set_dechirp", "pmd_load", "pmd_fft_peak", "pmd_mix_quantise",
     "pmd_get_spectrum",
 ]
@@ -310,6 +311,16 @@ def dsp_lib():
     L.symd_destroy.argtypes = [C.c_void_p]
     L.symd_destroy.restype = None
     L.symd_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.symd_store_reset.argtypes = [C.c_void_p]
+    L.symd_store_slide.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.symd_store_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.symd_store_scan.argtypes = [C.c_void_p, C.c_int]
+    L.isee3dsp_dev_alloc.restype = C.c_void_p
+    L.isee3dsp_dev_alloc.argtypes = [C.c_size_t]
+    L.isee3dsp_dev_free.argtypes = [C.c_void_p]
+    L.isee3dsp_dev_free.restype = None
+    L.isee3dsp_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.isee3dsp_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.symd_timesearch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_double)]
     L.symd_demod.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
@@ -344,6 +355,24 @@ class SymDemodEngine:
         s = np.ascontiguousarray(samples, dtype=np.int16)
         if self.L.symd_load(self.h, s.ctypes.data, len(s), 0) != 0:
             raise RuntimeError("symd_load: " + dsp_error())
+
+    # the window buffer kept in HBM (symdemod.c:96-125): memmove / append / prefix sums, see include/isee3_dsp_hip.h
+    def store_slide(self, slide, nsamples):
+        if self.L.symd_store_slide(self.h, int(slide), int(nsamples)) != 0:
+            raise RuntimeError("symd_store_slide: " + dsp_error())
+
+    def store_put(self, at, samples):
+        if isinstance(samples, DeviceBuffer):
+            rc = self.L.symd_store_put(self.h, int(at), samples.ptr, samples.nbytes // 2, 1)
+        else:
+            s = np.ascontiguousarray(samples, dtype=np.int16)
+            rc = self.L.symd_store_put(self.h, int(at), s.ctypes.data, len(s), 0)
+        if rc != 0:
+            raise RuntimeError("symd_store_put: " + dsp_error())
+
+    def store_scan(self, n):
+        if self.L.symd_store_scan(self.h, int(n)) != 0:
+            raise RuntimeError("symd_store_scan: " + dsp_error())
 
     def timesearch(self, lo, sw, symbolclocks, nsymbols, noff):
         sw = np.ascontiguousarray(sw, dtype=np.int32)
@@ -437,7 +466,8 @@ def cli_path(name):
 # ------------------------------------------------------------------------------------------------
 # libisee3chain.so : pmdemod | symdemod | vdecode on memory buffers (include/isee3_chain.h)
 # ------------------------------------------------------------------------------------------------
-CHAIN_SYMBOLS = ["isee3_chain_default_opts", "isee3_chain_run_mem", "isee3_chain_run_fd", "isee3_chain_last_error", "isee3_chain_release"]
+CHAIN_SYMBOLS = ["isee3_chain_default_opts", "isee3_chain_run_mem", "isee3_chain_run_dev", "isee3_chain_run_fd",
+                 "isee3_chain_last_error", "isee3_chain_last_stage_ms", "isee3_chain_release"]
 
 
 class ChainOpts(C.Structure):
@@ -462,6 +492,9 @@ def chain_lib():
     L.isee3_chain_default_opts.argtypes = [C.POINTER(ChainOpts)]
     L.isee3_chain_run_mem.argtypes = [C.POINTER(ChainOpts), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_size_t)]
+    L.isee3_chain_run_dev.argtypes = L.isee3_chain_run_mem.argtypes
+    L.isee3_chain_last_stage_ms.argtypes = [C.POINTER(C.c_double * 3)]
+    L.isee3_chain_last_stage_ms.restype = None
     L.isee3_chain_run_fd.argtypes = [C.POINTER(ChainOpts), C.c_int, C.c_int]
     L.isee3_chain_last_error.restype = C.c_char_p
     _chain = L
@@ -469,27 +502,39 @@ def chain_lib():
 
 
 def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=200, flip=False,
-              search_freq=0.0, search_width=0.0):
-    """int16 interleaved IQ (numpy) -> decoded bits as bytes of '0'/'1' (whole chain on the GPU)."""
+              search_freq=0.0, search_width=0.0, stage_ms=None):
+    """int16 interleaved IQ -> decoded bits as bytes of '0'/'1' (whole chain on the GPU).  `iq` is a numpy array in host
+    memory (isee3_chain_run_mem) or a DeviceBuffer holding the capture in HBM (isee3_chain_run_dev).  stage_ms: optional
+    list that receives the ms spent inside the engine calls of [pmdemod, symdemod, vdecode]."""
     L = chain_lib()
-    iq = np.ascontiguousarray(iq, dtype=np.int16)
     o = ChainOpts()
     L.isee3_chain_default_opts(C.byref(o))
     o.samprate, o.binsize, o.decode_delay, o.flip = samprate, binsize, decode_delay, int(flip)
     o.search_freq, o.search_width = search_freq, search_width
     o.symrate = None if symrate is None else str(symrate).encode()
+    on_dev = isinstance(iq, DeviceBuffer)
+    if on_dev:
+        nvals, ptr = iq.nbytes // 2, iq.ptr
+    else:
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        nvals, ptr = len(iq), iq.ctypes.data
     # decoded bits <= symbols / 2; symbols = duration x the rate `symdemod -c` resolves to (symdemod.c:67-77).  10 % and
     # 4 KiB of head room; the library reports a short write as an error instead of truncating.
     if symrate is None:
         rate = 1024.545058
     else:
         rate = float(symrate) if "." in str(symrate) else float(symrate) * 1024.545058 / 1024.0
-    cap = min(len(iq) // 4 + 4096, int(len(iq) / 2 / samprate * rate / 2 * 1.1) + 4096)
+    cap = min(nvals // 4 + 4096, int(nvals / 2 / samprate * rate / 2 * 1.1) + 4096)
     out = C.create_string_buffer(cap)
     n = C.c_size_t(0)
-    rc = L.isee3_chain_run_mem(C.byref(o), iq.ctypes.data, len(iq) // 2, out, cap, C.byref(n))
+    fn = L.isee3_chain_run_dev if on_dev else L.isee3_chain_run_mem
+    rc = fn(C.byref(o), ptr, nvals // 2, out, cap, C.byref(n))
     if rc != 0:
-        raise RuntimeError("isee3_chain_run_mem: " + (L.isee3_chain_last_error() or b"").decode())
+        raise RuntimeError("isee3_chain_run: " + (L.isee3_chain_last_error() or b"").decode())
+    if stage_ms is not None:
+        ms = (C.c_double * 3)()
+        L.isee3_chain_last_stage_ms(C.byref(ms))
+        stage_ms[:] = [ms[0], ms[1], ms[2]]
     return out.raw[:n.value]
 
 

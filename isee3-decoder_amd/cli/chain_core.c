@@ -1,8 +1,11 @@
 /* chain_core.c -- pmdemod | symdemod | vdecode in ONE process (libisee3chain.so, bin/isee3chain): the three reference pipe stages
- * (pmdemod.c, symdemod.c, vdecode.c) run as threads of one program connected by pipe(2), so they
- * share one HIP context and one GPU instead of paying three process start-ups.  Each stage is
- * exactly the code of the stand-alone binary (the cli/ *_core.c files); stdin = int16 I,Q pairs, stdout = ASCII
- * '0'/'1'.  Options: the union of the stages' options that matter for a chain:
+ * (pmdemod.c, symdemod.c, vdecode.c) run as threads of one program, so they share one HIP context and one GPU
+ * instead of paying three process start-ups.  Each stage is exactly the code of the stand-alone binary (the
+ * cli/ *_core.c files).  The sample streams stay in HBM: pmdemod writes each baseband block into a device slot of a
+ * small ring, symdemod copies it (device to device) into its device-resident two-window buffer; a capture that is
+ * already in device memory is read in place.  Only the soft symbols (1 kB per second of signal) and the decoded bits
+ * cross to the host.  stdin = int16 I,Q pairs, stdout = ASCII '0'/'1'.
+ * Options: the union of the stages' options that matter for a chain:
  *     -r Hz  sample rate (pmdemod -r, symdemod -r)        -b Hz  FFT bin size (pmdemod -b)
  *     -c Hz  symbol rate (symdemod -c)                    -d n   decode delay (vdecode -d)
  *     -W Hz / -S Hz / -f  pmdemod search width / start / flip          -v  keep the stages' status lines
@@ -14,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 #include "pmdemod_core.h"
 #include "symdemod_core.h"
@@ -55,20 +59,33 @@ static void *pm_create(int n) {
 }
 #define PMH(x) (((dsp_ctx *)(x))->h)
 static int pm_dechirp(void *h, const double *t) { return pmd_set_dechirp(PMH(h), t); }
-static int pm_load(void *h, const int16_t *iq, int flip) { return pmd_load(PMH(h), iq, 0, flip); }
+/* time spent inside engine calls, per stage (they include the waits for the GPU): isee3_chain_last_stage_ms() */
+static __thread double t_stage_ms;
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+#define TIMED(expr) do { double t0_ = now_ms(); int r_ = (expr); t_stage_ms += now_ms() - t0_; return r_; } while (0)
+static int pm_load(void *h, const int16_t *iq, int flip) { TIMED(pmd_load(PMH(h), iq, 0, flip)); }
+static int pm_load_dev(void *h, const int16_t *iq, int flip) { TIMED(pmd_load(PMH(h), iq, 1, flip)); }
 static int pm_peak(void *h, int a, int b, pmdemod_peak *o) {
   pmd_peak p;
-  if (pmd_fft_peak(PMH(h), a, b, &p) != 0) return -1;
+  double t0 = now_ms();
+  int rc = pmd_fft_peak(PMH(h), a, b, &p);
+  t_stage_ms += now_ms() - t0;
+  if (rc != 0) return -1;
   o->peak = p.peak; o->maxenergy = p.maxenergy; o->peak_re = p.peak_re; o->peak_im = p.peak_im;
   o->next_re = p.next_re; o->next_im = p.next_im; o->prev_re = p.prev_re; o->prev_im = p.prev_im;
   return 0;
 }
-static int pm_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) {
+static int pm_mix_any(void *h, double cstep, pmdemod_mix *r, int16_t *out16, int out_is_dev) {
   pmd_mix m;
-  if (pmd_mix_quantise(PMH(h), cstep, &m, out16, NULL, 0) != 0) return -1;
+  double t0 = now_ms();
+  int rc = pmd_mix_quantise(PMH(h), cstep, &m, out16, NULL, out_is_dev);
+  t_stage_ms += now_ms() - t0;
+  if (rc != 0) return -1;
   r->dc_re = m.dc_re; r->dc_im = m.dc_im; r->amplitude = m.amplitude; r->diffsumsq = m.diffsumsq;
   return 0;
 }
+static int pm_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) { return pm_mix_any(h, cstep, r, out16, 0); }
+static int pm_mix_dev(void *h, double cstep, pmdemod_mix *r, int16_t *d_out16) { return pm_mix_any(h, cstep, r, d_out16, 1); }
 static void pm_destroy(void *p) {
   dsp_ctx *c = p;
   if (!c) return;
@@ -80,13 +97,17 @@ static void *sy_create(int n) {
   dsp_ctx *c = malloc(sizeof *c);
   if (!c) return NULL;
   c->n = n; c->h = pool_take(g_sy_pool, n);
-  if (!c->h) c->h = symd_create(n);
+  if (c->h) symd_store_reset(c->h);                 /* a kept handle: its window buffer starts out zero again */
+  else c->h = symd_create(n);
   if (!c->h) { free(c); return NULL; }
   return c;
 }
-static int sy_load(void *h, const int16_t *s, int n) { return symd_load(PMH(h), s, n, 0); }
-static int sy_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) { return symd_timesearch(PMH(h), lo, sw, sc, ns, noff, en); }
-static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o, double *es) { return symd_demod(PMH(h), e, sc, ns, g, o, 0, es); }
+static int sy_load(void *h, const int16_t *s, int n) { TIMED(symd_load(PMH(h), s, n, 0)); }
+static int sy_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) { TIMED(symd_timesearch(PMH(h), lo, sw, sc, ns, noff, en)); }
+static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o, double *es) { TIMED(symd_demod(PMH(h), e, sc, ns, g, o, 0, es)); }
+static int sy_slide(void *h, int slide, int n) { TIMED(symd_store_slide(PMH(h), slide, n)); }
+static int sy_put(void *h, int at, const int16_t *src, int n, int dev) { TIMED(symd_store_put(PMH(h), at, src, n, dev)); }
+static int sy_scan(void *h, int n) { TIMED(symd_store_scan(PMH(h), n)); }
 static void sy_destroy(void *p) {
   dsp_ctx *c = p;
   if (!c) return;
@@ -123,6 +144,7 @@ static void vd_destroy(void *p) {
   pthread_mutex_unlock(&g_pool_mu);
   vd_free(c);                                  /* pool full */
 }
+static void slot_pool_release(void);
 void isee3_chain_release(void) {
   pthread_mutex_lock(&g_pool_mu);
   for (int i = 0; i < VD_POOL; i++) { vd_free(g_pool[i]); g_pool[i] = NULL; }
@@ -133,6 +155,7 @@ void isee3_chain_release(void) {
     if (g_sy_pool[i].h) { symd_destroy(g_sy_pool[i].h); g_sy_pool[i].h = NULL; }
   }
   pthread_mutex_unlock(&g_hpool_mu);
+  slot_pool_release();
 }
 static void *vd_create(int len) {
   vd_ctx *c = NULL;
@@ -151,7 +174,7 @@ static void *vd_create(int len) {
 }
 static int vd_init(void *h, int s) { return init_viterbi224(((vd_ctx *)h)->d[0], s); }
 static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) {
-  return v224hip_stream_decode(((vd_ctx *)h)->d[0], s, n, d, o);
+  TIMED(v224hip_stream_decode(((vd_ctx *)h)->d[0], s, n, d, o));
 }
 #define VD_SPLIT_WARM (4 * 1020)
 static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigned char *o) {
@@ -173,83 +196,164 @@ static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigne
   return rc;
 }
 
-/* ---- in-memory channel pmdemod -> symdemod: a byte ring with read(2) semantics on one side and a stdio stream
- * (fopencookie) on the other; a pipe costs two kernel copies and a syscall per 64 KiB of a 2 B/sample stream ---- */
+/* ---- block channel pmdemod -> symdemod: a ring of device slots, each one baseband block (N int16).  pmdemod acquires
+ * a free slot, lets the engine write the block into it, commits it; symdemod takes views of committed slots in order
+ * and copies them device-to-device into its window buffer.  No sample passes through host memory. ---- */
+#define NSLOT 3
 typedef struct {
-  pthread_mutex_t mu; pthread_cond_t can_read, can_write;
-  unsigned char *buf; size_t cap, head, count; int closed, reader_gone;
-} chan;
-static chan *chan_new(size_t cap) {
-  chan *c = calloc(1, sizeof *c);
-  if (!c) return NULL;
-  c->buf = malloc(cap); c->cap = cap;
-  if (!c->buf) { free(c); return NULL; }
-  pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->can_read, NULL); pthread_cond_init(&c->can_write, NULL);
-  return c;
+  pthread_mutex_t mu; pthread_cond_t cv;
+  int16_t *slot[NSLOT]; int N;
+  int q[NSLOT], qhead, qcount;            /* committed slots, FIFO */
+  int isfree[NSLOT];
+  int closed, reader_gone;
+  int cur, cur_pos;                       /* slot being consumed by the reader (-1: none) */
+} blkchan;
+
+/* slots of finished calls are kept (device allocations of up to 16 MiB each), keyed by block size */
+#define SLOT_POOL 8
+static pthread_mutex_t g_slot_mu = PTHREAD_MUTEX_INITIALIZER;
+static struct { int16_t *p; int N; } g_slot_pool[SLOT_POOL];
+static int16_t *slot_take(int N) {
+  int16_t *p = NULL;
+  pthread_mutex_lock(&g_slot_mu);
+  for (int i = 0; i < SLOT_POOL; i++) if (g_slot_pool[i].p && g_slot_pool[i].N == N) { p = g_slot_pool[i].p; g_slot_pool[i].p = NULL; break; }
+  pthread_mutex_unlock(&g_slot_mu);
+  return p ? p : isee3dsp_dev_alloc(sizeof(int16_t) * (size_t)N);
 }
-static void chan_free(chan *c) { if (c) { free(c->buf); free(c); } }
-static ssize_t chan_write(void *p, const char *b, size_t n) {
-  chan *c = p; size_t done = 0;
-  pthread_mutex_lock(&c->mu);
-  while (done < n) {
-    while (c->count == c->cap && !c->reader_gone) pthread_cond_wait(&c->can_write, &c->mu);
-    if (c->reader_gone) { pthread_mutex_unlock(&c->mu); return 0; }      /* like EPIPE: the stream goes into error */
-    size_t tail = (c->head + c->count) % c->cap, room = c->cap - c->count;
-    size_t k = n - done < room ? n - done : room;
-    if (k > c->cap - tail) k = c->cap - tail;
-    memcpy(c->buf + tail, b + done, k);
-    c->count += k; done += k;
-    pthread_cond_signal(&c->can_read);
-  }
-  pthread_mutex_unlock(&c->mu);
-  return (ssize_t)n;
+static void slot_give(int16_t *p, int N) {
+  if (!p) return;
+  pthread_mutex_lock(&g_slot_mu);
+  for (int i = 0; i < SLOT_POOL; i++) if (!g_slot_pool[i].p) { g_slot_pool[i].p = p; g_slot_pool[i].N = N; p = NULL; break; }
+  pthread_mutex_unlock(&g_slot_mu);
+  if (p) isee3dsp_dev_free(p);
 }
-static int chan_close(void *p) {
-  chan *c = p;
-  pthread_mutex_lock(&c->mu); c->closed = 1; pthread_cond_broadcast(&c->can_read); pthread_mutex_unlock(&c->mu);
-  return 0;
-}
-static long chan_read(void *p, void *b, unsigned long n) {       /* whole int16 samples only */
-  chan *c = p;
-  if (n < 2) return 0;
-  pthread_mutex_lock(&c->mu);
-  while (c->count < 2 && !c->closed) pthread_cond_wait(&c->can_read, &c->mu);
-  size_t k = c->count & ~(size_t)1;
-  if (k > (n & ~1ul)) k = n & ~1ul;
-  if (k > c->cap - c->head) k = (c->cap - c->head) & ~(size_t)1;
-  if (k == 0 && c->count >= 2) {                                   /* a sample straddles the wrap: hand it over alone */
-    unsigned char *o = b; o[0] = c->buf[c->head]; o[1] = c->buf[(c->head + 1) % c->cap]; k = 2;
-  } else memcpy(b, c->buf + c->head, k);
-  c->head = (c->head + k) % c->cap; c->count -= k;
-  pthread_cond_signal(&c->can_write);
-  pthread_mutex_unlock(&c->mu);
-  return (long)k;
+static void slot_pool_release(void) {
+  pthread_mutex_lock(&g_slot_mu);
+  for (int i = 0; i < SLOT_POOL; i++) if (g_slot_pool[i].p) { isee3dsp_dev_free(g_slot_pool[i].p); g_slot_pool[i].p = NULL; }
+  pthread_mutex_unlock(&g_slot_mu);
 }
 
-typedef struct { pmdemod_opts o; FILE *in, *out; int rc; } pm_arg;
-typedef struct { symdemod_opts o; chan *in; FILE *out; int rc; } sy_arg;
-typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; } vd_arg;
+static void blk_init(blkchan *c) {
+  memset(c, 0, sizeof *c);
+  pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->cv, NULL);
+  c->cur = -1;
+}
+static void blk_free(blkchan *c) { for (int i = 0; i < NSLOT; i++) { slot_give(c->slot[i], c->N); c->slot[i] = NULL; } }
+/* pmdemod side */
+static int16_t *blk_acquire(void *p, int N, int *is_dev) {
+  blkchan *c = p;
+  int16_t *r = NULL;
+  pthread_mutex_lock(&c->mu);
+  if (c->N == 0) {                                   /* first block: now the size is known */
+    c->N = N;
+    for (int i = 0; i < NSLOT; i++) { c->slot[i] = slot_take(N); c->isfree[i] = c->slot[i] != NULL; }
+  }
+  for (;;) {
+    int k = -1;
+    for (int i = 0; i < NSLOT; i++) if (c->isfree[i]) { k = i; break; }
+    if (k >= 0) { c->isfree[k] = 0; r = c->slot[k]; break; }
+    if (!c->slot[0] || !c->slot[1]) break;           /* allocation failed */
+    if (c->reader_gone) { r = c->slot[0]; break; }   /* nobody listens any more: any slot will do */
+    pthread_cond_wait(&c->cv, &c->mu);
+  }
+  pthread_mutex_unlock(&c->mu);
+  *is_dev = 1;
+  return r;
+}
+static int blk_commit(void *p, int16_t *buf, int N) {
+  blkchan *c = p;
+  (void)N;
+  pthread_mutex_lock(&c->mu);
+  int k = -1;
+  for (int i = 0; i < NSLOT; i++) if (c->slot[i] == buf) k = i;
+  if (k >= 0) {
+    if (c->reader_gone) c->isfree[k] = 1;
+    else { c->q[(c->qhead + c->qcount) % NSLOT] = k; c->qcount++; }
+  }
+  pthread_cond_broadcast(&c->cv);
+  pthread_mutex_unlock(&c->mu);
+  return k >= 0 ? 0 : -1;
+}
+static void blk_close(blkchan *c) {
+  pthread_mutex_lock(&c->mu); c->closed = 1; pthread_cond_broadcast(&c->cv); pthread_mutex_unlock(&c->mu);
+}
+/* symdemod side: a view of up to max samples; the previous view's slot is released first (its copy is done: the
+ * engine's store_put returns after a device-to-device copy has finished) */
+static long blk_next(void *p, const int16_t **blk, int *is_dev, long max) {
+  blkchan *c = p;
+  long n = 0;
+  pthread_mutex_lock(&c->mu);
+  if (c->cur >= 0 && c->cur_pos >= c->N) { c->isfree[c->cur] = 1; c->cur = -1; pthread_cond_broadcast(&c->cv); }
+  while (c->cur < 0) {
+    if (c->qcount > 0) { c->cur = c->q[c->qhead]; c->qhead = (c->qhead + 1) % NSLOT; c->qcount--; c->cur_pos = 0; break; }
+    if (c->closed) break;
+    pthread_cond_wait(&c->cv, &c->mu);
+  }
+  if (c->cur >= 0) {
+    n = c->N - c->cur_pos < max ? c->N - c->cur_pos : max;
+    *blk = c->slot[c->cur] + c->cur_pos; *is_dev = 1;
+    c->cur_pos += (int)n;
+  }
+  pthread_mutex_unlock(&c->mu);
+  return n;
+}
+static void blk_reader_gone(blkchan *c) {
+  pthread_mutex_lock(&c->mu);
+  c->reader_gone = 1;
+  if (c->cur >= 0) { c->isfree[c->cur] = 1; c->cur = -1; }
+  while (c->qcount > 0) { c->isfree[c->q[c->qhead]] = 1; c->qhead = (c->qhead + 1) % NSLOT; c->qcount--; }
+  pthread_cond_broadcast(&c->cv);
+  pthread_mutex_unlock(&c->mu);
+}
+
+/* ---- where pmdemod's blocks come from: a capture in memory (host or device: views, no copy) or a FILE ---- */
+typedef struct { const int16_t *iq; size_t nsamples, pos; int is_dev; FILE *f; int16_t *buf; } iq_src;
+static int iq_next(void *p, int N, const int16_t **blk, int *is_dev) {
+  iq_src *s = p;
+  if (s->f) {
+    if (!s->buf && !(s->buf = malloc(sizeof(int16_t) * 2 * (size_t)N))) return -1;
+    if (fread(s->buf, 4, (size_t)N, s->f) < (size_t)N) return 0;
+    *blk = s->buf; *is_dev = 0;
+    return 1;
+  }
+  if (s->pos + (size_t)N > s->nsamples) return 0;      /* a partial block is dropped (pmdemod.c:206-216) */
+  *blk = s->iq + 2 * s->pos; *is_dev = s->is_dev;
+  s->pos += (size_t)N;
+  return 1;
+}
+
+typedef struct { pmdemod_opts o; iq_src src; blkchan *out; int rc; double ms; } pm_arg;
+typedef struct { symdemod_opts o; blkchan *in; FILE *out; int rc; double ms; } sy_arg;
+typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; } vd_arg;
 
 static void *pm_thread(void *p) {
   pm_arg *a = p;
-  pmdemod_engine e = { pm_create, pm_dechirp, pm_load, pm_peak, pm_mix, pm_destroy };
-  a->rc = pmdemod_run(&a->o, &e, a->in, a->out, stderr, NULL, 0, NULL);
-  fclose(a->out);
+  pmdemod_engine e = { pm_create, pm_dechirp, pm_load, pm_peak, pm_mix, pm_destroy, pm_load_dev, pm_mix_dev };
+  pmdemod_source src = { iq_next, &a->src };
+  pmdemod_sink dst = { blk_acquire, blk_commit, a->out };
+  t_stage_ms = 0;
+  a->rc = pmdemod_run_io(&a->o, &e, &src, &dst, a->src.f, stderr, NULL, 0, NULL);
+  a->ms = t_stage_ms;
+  blk_close(a->out);
   return NULL;
 }
 static void *sy_thread(void *p) {
   sy_arg *a = p;
-  symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy };
-  a->rc = symdemod_run_rd(&a->o, &e, chan_read, a->in, a->out, stderr);
+  symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy, sy_slide, sy_put, sy_scan };
+  t_stage_ms = 0;
+  a->rc = symdemod_run_blk(&a->o, &e, blk_next, a->in, a->out, stderr);
+  a->ms = t_stage_ms;
   fclose(a->out);
-  pthread_mutex_lock(&a->in->mu); a->in->reader_gone = 1; pthread_cond_broadcast(&a->in->can_write); pthread_mutex_unlock(&a->in->mu);
+  blk_reader_gone(a->in);
   return NULL;
 }
 static void *vd_thread(void *p) {
   vd_arg *a = p;
   vdecode_result r;
   vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk, vd_whole };
+  t_stage_ms = 0;
   a->rc = vdecode_run(&a->o, &e, a->fd_in, a->out, stderr, &r);
+  a->ms = t_stage_ms;
   fflush(a->out);
   close(a->fd_in);
   return NULL;
@@ -257,43 +361,46 @@ static void *vd_thread(void *p) {
 
 
 static __thread char g_chain_err[256];
+static __thread double g_stage_ms[3];
 const char *isee3_chain_last_error(void) { return g_chain_err; }
+void isee3_chain_last_stage_ms(double ms[3]) { ms[0] = g_stage_ms[0]; ms[1] = g_stage_ms[1]; ms[2] = g_stage_ms[2]; }
 
 void isee3_chain_default_opts(isee3_chain_opts *o) {
   memset(o, 0, sizeof *o);
   o->samprate = 250000; o->binsize = 4; o->decode_delay = 200;
 }
 
-static int chain_run(const isee3_chain_opts *co, FILE *in, FILE *out, int finite_input) {
+static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   pm_arg pa; sy_arg sa; vd_arg va;
   int p2[2];
-  chan *c1 = chan_new((size_t)64 << 20);
-  cookie_io_functions_t cio = { NULL, chan_write, NULL, chan_close };
+  blkchan c1;
   pmdemod_default_opts(&pa.o); symdemod_default_opts(&sa.o); vdecode_default_opts(&va.o);
   pa.o.argv0 = "isee3chain/pmdemod"; sa.o.argv0 = "isee3chain/symdemod"; va.o.argv0 = "isee3chain/vdecode";
   pa.o.samprate = co->samprate; sa.o.samprate = (int)co->samprate;
   pa.o.binsize = co->binsize; pa.o.search_freq = co->search_freq; pa.o.search_width = co->search_width; pa.o.flip = co->flip;
   if (co->symrate) symdemod_set_symrate(&sa.o, co->symrate);   /* symdemod -c semantics; no getopt in a library that runs concurrent chains */
   va.o.decode_delay = co->decode_delay;
-  /* a capture in memory is finite and nobody waits for early bits: let vdecode see the whole symbol stream at once.
-   * ISEE3_CHAIN_WHOLE=0 / 1 overrides. */
-  (void)finite_input;   /* measured: at 30 k bits per capture the second decoder and the lost overlap with pmdemod/symdemod cost more than the split saves (72 vs 57 ms) */
+  /* measured: at 30 k bits per capture a second decoder and the lost overlap with pmdemod / symdemod cost more than the
+   * split saves (72 vs 57 ms), so vdecode works block by block unless ISEE3_CHAIN_WHOLE=1 */
   va.o.whole_input = getenv("ISEE3_CHAIN_WHOLE") ? atoi(getenv("ISEE3_CHAIN_WHOLE")) : 0;
   pa.o.quiet = sa.o.quiet = va.o.quiet = !co->verbose;
   pthread_once(&g_chunk_once, chunk_from_env);
-  if (!c1 || pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() / channel allocation failed"); chan_free(c1); return 2; }
+  if (pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() failed"); return 2; }
 #ifdef F_SETPIPE_SZ
   fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);
 #endif
-  pa.in = in; pa.out = fopencookie(c1, "w", cio);
-  sa.in = c1; sa.out = fdopen(p2[1], "w");
+  blk_init(&c1);
+  pa.src = *src; pa.out = &c1;
+  sa.in = &c1; sa.out = fdopen(p2[1], "w");
   va.fd_in = p2[0]; va.out = out;
   pthread_t t1, t2, t3;
   pthread_create(&t1, NULL, pm_thread, &pa);
   pthread_create(&t2, NULL, sy_thread, &sa);
   pthread_create(&t3, NULL, vd_thread, &va);
   pthread_join(t1, NULL); pthread_join(t2, NULL); pthread_join(t3, NULL);
-  chan_free(c1);
+  blk_free(&c1);
+  free(pa.src.buf);
+  g_stage_ms[0] = pa.ms; g_stage_ms[1] = sa.ms; g_stage_ms[2] = va.ms;
   if (pa.rc || sa.rc || va.rc) {
     snprintf(g_chain_err, sizeof g_chain_err, "stage failed (pmdemod %d, symdemod %d, vdecode %d): %.80s / %.80s", pa.rc, sa.rc,
              va.rc, isee3dsp_last_error(), v224hip_last_error());
@@ -305,20 +412,27 @@ static int chain_run(const isee3_chain_opts *co, FILE *in, FILE *out, int finite
 int isee3_chain_run_fd(const isee3_chain_opts *o, int fd_in, int fd_out) {
   FILE *in = fdopen(dup(fd_in), "r"), *out = fdopen(dup(fd_out), "w");
   if (!in || !out) { snprintf(g_chain_err, sizeof g_chain_err, "fdopen failed"); return 2; }
-  int rc = chain_run(o, in, out, 0);
+  setvbuf(in, NULL, _IOFBF, 1 << 20);
+  iq_src src = { NULL, 0, 0, 0, in, NULL };
+  int rc = chain_run(o, &src, out);
   fclose(in); fclose(out);
   return rc;
 }
 
-int isee3_chain_run_mem(const isee3_chain_opts *o, const int16_t *iq, size_t nsamples, char *out, size_t cap, size_t *nout) {
-  FILE *in = fmemopen((void *)iq, nsamples * 4, "r");       /* the capture is read where it lies */
+static int run_memory(const isee3_chain_opts *o, const int16_t *iq, size_t nsamples, int is_dev, char *out, size_t cap, size_t *nout) {
   FILE *mo = fmemopen(out, cap, "w");
-  if (!in || !mo) { snprintf(g_chain_err, sizeof g_chain_err, "fmemopen failed"); return 2; }
-  setvbuf(in, NULL, _IOFBF, 1 << 20);                /* (unbuffered, glibc reads a memory stream byte by byte) */
+  if (!mo) { snprintf(g_chain_err, sizeof g_chain_err, "fmemopen failed"); return 2; }
   setvbuf(mo, NULL, _IONBF, 0);                       /* write straight into the caller's buffer */
-  int rc = chain_run(o, in, mo, 1);
+  iq_src src = { iq, nsamples, 0, is_dev, NULL, NULL };     /* the capture is read where it lies */
+  int rc = chain_run(o, &src, mo);
   long pos = ftell(mo);
-  fclose(mo); fclose(in);
+  fclose(mo);
   if (nout) *nout = pos > 0 ? (size_t)pos : 0;
   return rc;
+}
+int isee3_chain_run_mem(const isee3_chain_opts *o, const int16_t *iq, size_t nsamples, char *out, size_t cap, size_t *nout) {
+  return run_memory(o, iq, nsamples, 0, out, cap, nout);
+}
+int isee3_chain_run_dev(const isee3_chain_opts *o, const int16_t *d_iq, size_t nsamples, char *out, size_t cap, size_t *nout) {
+  return run_memory(o, d_iq, nsamples, 1, out, cap, nout);
 }

@@ -44,13 +44,46 @@ static double tau(double x) {                        /* Quinn's second estimator
        - sqrt(6.) / 24 * log((x + 1 - sqrt(2 / 3.)) / (x + 1 + sqrt(2 / 3.)));
 }
 
+/* FILE-based source and sink: the stand-alone pipe stage */
+typedef struct { FILE *f; int16_t *buf; } file_src;
+static int file_next(void *p, int N, const int16_t **blk, int *is_dev) {
+  file_src *s = p;
+  if (!s->buf && !(s->buf = malloc(sizeof(int16_t) * 2 * (size_t)N))) return -1;
+  if (fread(s->buf, 4, (size_t)N, s->f) < (size_t)N) return 0;
+  *blk = s->buf; *is_dev = 0;
+  return 1;
+}
+typedef struct { FILE *f; int16_t *buf; } file_dst;
+static int16_t *file_acquire(void *p, int N, int *is_dev) {
+  file_dst *d = p;
+  if (!d->buf) d->buf = malloc(sizeof(int16_t) * (size_t)N);
+  *is_dev = 0;
+  return d->buf;
+}
+static int file_commit(void *p, int16_t *buf, int N) {
+  file_dst *d = p;
+  fwrite(buf, sizeof(int16_t), (size_t)N, d->f);
+  fflush(d->f);
+  return 0;
+}
+
 int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *out, FILE *err,
                 pmdemod_block_report *report, int report_cap, int *nreport) {
+  file_src fs = { in, NULL };
+  file_dst fd = { out, NULL };
+  pmdemod_source src = { file_next, &fs };
+  pmdemod_sink dst = { file_acquire, file_commit, &fd };
+  int rc = pmdemod_run_io(o, e, &src, &dst, in, err, report, report_cap, nreport);
+  free(fs.buf); free(fd.buf);
+  return rc;
+}
+
+int pmdemod_run_io(const pmdemod_opts *o, const pmdemod_engine *e, const pmdemod_source *src, const pmdemod_sink *dst,
+                   FILE *in, FILE *err, pmdemod_block_report *report, int report_cap, int *nreport) {
   double Samprate = o->samprate, Search_width = o->search_width, Carrier_search_freq = o->search_freq;
   double cn0 = -999;
   int exitcode = 0, nb = 0;
   void *h = NULL;
-  int16_t *iq = NULL, *out16 = NULL;
   double *lo = NULL;
   long long total_samples = 0;
 
@@ -74,9 +107,7 @@ int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *
   if (o->flip && !o->quiet) fprintf(err, "%s: I & Q samples swapped (spectrum inverted)\n", o->argv0);
 
   h = e->create(N);
-  iq = malloc(sizeof(int16_t) * 2 * (size_t)N);
-  out16 = malloc(sizeof(int16_t) * (size_t)N);
-  if (!h || !iq || !out16) {
+  if (!h) {
     fprintf(err, "%s: cannot set up a %d-point FFT\n", o->argv0, N);
     exitcode = 2;
     goto done;
@@ -99,7 +130,7 @@ int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *
   }
   {
     struct stat sb;
-    if (!o->quiet && fstat(fileno(in), &sb) == 0 && S_ISREG(sb.st_mode)) {
+    if (!o->quiet && in && fstat(fileno(in), &sb) == 0 && S_ISREG(sb.st_mode)) {
       long long nsamples = sb.st_size / 4;
       fprintf(err, "%s: demodulating %'lld bytes; %'lld samples; %'.2lf sec @ %'.1lf Hz\n", o->argv0,
               (long long)sb.st_size, nsamples, nsamples / Samprate, Samprate);
@@ -108,9 +139,11 @@ int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *
 
   for (;;) {
     /* a whole block or nothing: the remainder of the input is dropped (pmdemod.c:206-216) */
-    size_t got = fread(iq, 4, (size_t)N, in);
-    if (got < (size_t)N) break;
-    if (e->load(h, iq, o->flip ? 1 : 0) != 0) { exitcode = 2; break; }
+    const int16_t *iq = NULL; int in_dev = 0;
+    int got = src->next(src->ctx, N, &iq, &in_dev);
+    if (got == 0) break;
+    if (got < 0 || (in_dev && !e->load_dev)) { exitcode = 2; break; }
+    if ((in_dev ? e->load_dev(h, iq, o->flip ? 1 : 0) : e->load(h, iq, o->flip ? 1 : 0)) != 0) { exitcode = 2; break; }
 
     int firstbin, lastbin;
     if (Search_width != 0 && cn0 > o->cn0_threshold) {       /* locked: search near the last carrier */
@@ -133,7 +166,10 @@ int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *
 
     double cstep = 2 * M_PI * carrier_freq / Samprate;
     pmdemod_mix mx;
-    if (e->mix(h, cstep, &mx, out16) != 0) { exitcode = 2; break; }
+    int out_dev = 0;
+    int16_t *out16 = dst->acquire(dst->ctx, N, &out_dev);
+    if (!out16 || (out_dev && !e->mix_dev)) { exitcode = 2; break; }
+    if ((out_dev ? e->mix_dev(h, cstep, &mx, out16) : e->mix(h, cstep, &mx, out16)) != 0) { exitcode = 2; break; }
     cn0 = 10 * log10(Samprate * mx.amplitude * mx.amplitude / (2 * mx.diffsumsq));
     if (cn0 > o->cn0_threshold) Carrier_search_freq = carrier_freq;
     if (!o->quiet)
@@ -142,13 +178,12 @@ int pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *
               cn0, cn0 >= o->cn0_threshold ? " locked" : "");
     if (report && nb < report_cap) { report[nb].peak = pk.peak; report[nb].carrier_freq = carrier_freq; report[nb].cn0 = cn0; }
     nb++;
-    fwrite(out16, sizeof(int16_t), (size_t)N, out);
-    fflush(out);
+    if (dst->commit(dst->ctx, out16, N) != 0) { exitcode = 2; break; }
     total_samples += N;
   }
 done:
   if (nreport) *nreport = nb;
   if (h) e->destroy(h);
-  free(iq); free(out16); free(lo);
+  free(lo);
   return exitcode;
 }

@@ -31,7 +31,26 @@ typedef struct {
   int   (*fft_peak)(void *h, int firstbin, int lastbin, pmdemod_peak *out);
   int   (*mix)(void *h, double cstep, pmdemod_mix *res, int16_t *out16);
   void  (*destroy)(void *h);
+  /* optional (needed by pmdemod_run_io when its source / sink hand out device memory): the same two calls on blocks
+     that are already, or shall stay, in device memory */
+  int   (*load_dev)(void *h, const int16_t *d_iq, int flip);
+  int   (*mix_dev)(void *h, double cstep, pmdemod_mix *res, int16_t *d_out16);
 } pmdemod_engine;
+
+/* where blocks come from / go to when they are not a FILE: views, so a capture in memory (host or device) is read in
+ * place and a consumer in the same process takes the baseband where the engine wrote it */
+typedef struct {
+  /* a view of the next N (I,Q) pairs; 1 = *blk valid until the next call, 0 = end of input (a partial block is dropped,
+     pmdemod.c:206-216), < 0 = error */
+  int (*next)(void *ctx, int N, const int16_t **blk, int *is_dev);
+  void *ctx;
+} pmdemod_source;
+typedef struct {
+  /* room for the next block's N int16 samples (host or device memory), then commit() publishes it */
+  int16_t *(*acquire)(void *ctx, int N, int *is_dev);
+  int (*commit)(void *ctx, int16_t *buf, int N);
+  void *ctx;
+} pmdemod_sink;
 
 typedef struct { int peak; double carrier_freq, cn0; } pmdemod_block_report;
 
@@ -41,4 +60,8 @@ int  pmdemod_parse_args(pmdemod_opts *o, int argc, char **argv, FILE *err);
 /* returns the process exit code of pmdemod.c (0, 1, 2); report/nreport optional per-block log */
 int  pmdemod_run(const pmdemod_opts *o, const pmdemod_engine *e, FILE *in, FILE *out, FILE *err,
                  pmdemod_block_report *report, int report_cap, int *nreport);
+/* the same stage between a block source and a block sink (in_for_stat: optional FILE whose size goes into the
+ * "demodulating ..." status line, as pmdemod.c:178-203 prints for a regular file) */
+int  pmdemod_run_io(const pmdemod_opts *o, const pmdemod_engine *e, const pmdemod_source *src, const pmdemod_sink *dst,
+                    FILE *in_for_stat, FILE *err, pmdemod_block_report *report, int report_cap, int *nreport);
 #endif

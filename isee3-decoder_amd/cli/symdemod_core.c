@@ -104,7 +104,21 @@ int symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, FI
   return symdemod_run_rd(o, e, fd_reader, &fd_in, out, err);
 }
 
+static int run(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader rd, symdemod_block_reader next, void *rctx,
+               FILE *out, FILE *err);
 int symdemod_run_rd(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader rd, void *rctx, FILE *out, FILE *err) {
+  return run(o, e, rd, NULL, rctx, out, err);
+}
+int symdemod_run_blk(const symdemod_opts *o, const symdemod_engine *e, symdemod_block_reader next, void *rctx, FILE *out, FILE *err) {
+  if (!e->store_slide || !e->store_put || !e->store_scan) return -1;
+  return run(o, e, NULL, next, rctx, out, err);
+}
+
+/* one window loop for both forms: `store` = the sample buffer lives in the engine (views from next()), else in
+ * samples[] here (bytes from rd()) and goes to the engine whole, once per window */
+static int run(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader rd, symdemod_block_reader next, void *rctx,
+               FILE *out, FILE *err) {
+  const int store = next != NULL;
   fesetround(FE_TONEAREST);                          /* symdemod.c:48 */
   int Samprate = o->samprate;
   double Symrate = o->symrate, window = o->window;
@@ -118,29 +132,38 @@ int symdemod_run_rd(const symdemod_opts *o, const symdemod_engine *e, symdemod_r
   int nsamples = 0, rc = -1;
   long long total_samples = 0, total_symbols = 0;
   int slack = (int)Symbolsamples + 64;
-  int16_t *samples = calloc((size_t)fullwater + (size_t)slack, sizeof *samples);  /* ref: malloc */
+  int16_t *samples = store ? NULL : calloc((size_t)fullwater + (size_t)slack, sizeof *samples);  /* ref: malloc */
   uint8_t *obuf = malloc((size_t)(window * 1.5 * Samprate / 2) + 4096);
   ctx_t c = { e, NULL, o->symbolclocks, NULL, 0, NULL, 0 };
   c.h = e->create(fullwater + slack);
-  if (!samples || !obuf || !c.h) goto done;
+  if ((!store && !samples) || !obuf || !c.h) goto done;
 
   for (;;) {
     if (firstsample >= window * Samprate) {          /* purge old samples, keep 2 symbols of slop */
       int slide = (int)(firstsample - 2 * Symbolsamples);
       if (slide > nsamples) slide = nsamples;
-      memmove(samples, samples + slide, sizeof(*samples) * (size_t)(nsamples - slide));
+      if (store) { if (e->store_slide(c.h, slide, nsamples) != 0) goto done; }
+      else memmove(samples, samples + slide, sizeof(*samples) * (size_t)(nsamples - slide));
       nsamples -= slide; firstsample -= slide; total_samples += slide;
     }
     while (nsamples < fullwater) {
-      long cnt = rd(rctx, samples + nsamples, sizeof(*samples) * (unsigned long)(fullwater - nsamples));
-      if (cnt <= 0) break;
-      nsamples += (int)(cnt / (long)sizeof(*samples));
+      if (store) {
+        const int16_t *blk = NULL; int is_dev = 0;
+        long cnt = next(rctx, &blk, &is_dev, fullwater - nsamples);
+        if (cnt <= 0) break;
+        if (e->store_put(c.h, nsamples, blk, (int)cnt, is_dev) != 0) goto done;
+        nsamples += (int)cnt;
+      } else {
+        long cnt = rd(rctx, samples + nsamples, sizeof(*samples) * (unsigned long)(fullwater - nsamples));
+        if (cnt <= 0) break;
+        nsamples += (int)(cnt / (long)sizeof(*samples));
+      }
     }
     if (nsamples < window * Samprate) break;
 
     /* the whole buffer goes to the engine, stale tail included: the reference's search can run a
        little past nsamples near end of input and reads whatever the buffer holds there */
-    if (e->load(c.h, samples, fullwater + slack) != 0) goto done;
+    if (store ? e->store_scan(c.h, fullwater + slack) != 0 : e->load(c.h, samples, fullwater + slack) != 0) goto done;
 
     int symphase = 0;
     double maxenergy = 0;

@@ -24,6 +24,14 @@ typedef struct {
   int   (*timesearch)(void *h, int lo, const int *sw, int symbolclocks, int nsymbols, int noff, double *energies);
   int   (*demod)(void *h, const int *edges, int symbolclocks, int nsymbols, double gain, uint8_t *out, double *energy_sum);
   void  (*destroy)(void *h);
+  /* optional (all three or none; needed by symdemod_run_blk): the two-window sample buffer of symdemod.c:96-125 kept
+     inside the engine (in HBM), zero-filled at create:
+       store_slide == memmove(buf, buf + slide, nsamples - slide), the rest of the buffer unchanged
+       store_put   == copy n samples (host or device memory) to buf[at..)
+       store_scan  == make buf[0..n) the window that timesearch / demod work on (what load() does after its copy) */
+  int   (*store_slide)(void *h, int slide, int nsamples);
+  int   (*store_put)(void *h, int at, const int16_t *src, int n, int src_is_dev);
+  int   (*store_scan)(void *h, int n);
 } symdemod_engine;
 
 void symdemod_default_opts(symdemod_opts *o);
@@ -35,4 +43,9 @@ int  symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, F
  * of a file descriptor -- the in-process chain hands blocks over in memory */
 typedef long (*symdemod_reader)(void *ctx, void *buf, unsigned long nbytes);
 int  symdemod_run_rd(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader rd, void *rctx, FILE *out, FILE *err);
+/* the same stage fed with VIEWS of sample blocks that may lie in device memory: next(ctx, &blk, &is_dev, max) hands out
+ * up to max samples (> 0; *blk stays valid until the next call) or 0 at end of input; the samples go straight into
+ * the engine's store, never through host memory */
+typedef long (*symdemod_block_reader)(void *ctx, const int16_t **blk, int *is_dev, long max_samples);
+int  symdemod_run_blk(const symdemod_opts *o, const symdemod_engine *e, symdemod_block_reader next, void *rctx, FILE *out, FILE *err);
 #endif

@@ -39,6 +39,16 @@ extern "C" int isee3dsp_set_device(int dev) {
     }                                                                                            \
   } while (0)
 
+extern "C" void *isee3dsp_dev_alloc(size_t bytes) {
+  void *d = nullptr;
+  if (g_device >= 0 && hipSetDevice(g_device) != hipSuccess) return nullptr;
+  if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return d;
+}
+extern "C" void isee3dsp_dev_free(void *d) { if (d) (void)hipFree(d); }
+extern "C" int isee3dsp_h2d(void *d, const void *h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+extern "C" int isee3dsp_d2h(void *h, const void *d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+
 static int grow(void **p, size_t *cap, size_t need) {
   if (*cap >= need) return 0;
   if (*p) (void)hipFree(*p);
@@ -51,19 +61,22 @@ static int grow(void **p, size_t *cap, size_t need) {
 // ===========================================================================================
 // symdemod
 // ===========================================================================================
-#define SCAN_PER_THREAD 16
-#define SCAN_BLOCK (256 * SCAN_PER_THREAD)
+#define SCAN_BLOCK 4096                      // samples per workgroup (two rounds of 256 threads x 8)
+#define SCAN_ROW 264                         // LDS row stride (8-byte words) of the transposed prefix image
 
 struct Symd {
   int dev; hipStream_t st;
   int cap, n;
-  int16_t *d_s; long long *d_P; long long *d_blk; int nblk_cap;
+  int16_t *d_s, *d_s2;                       // the window buffer and its ping-pong partner (store_slide)
+  long long *d_P; long long *d_blk; int nblk_cap;
   void *d_idx; size_t idx_cap;
   void *d_e; size_t e_cap;
   void *d_out; size_t out_cap;
   void *d_sym; size_t sym_cap;
   void *d_part; size_t part_cap;
+  void *d_terms; size_t terms_cap;
   unsigned *d_flag;
+  int inexact_last;                          // the previous window's sums left the exactly-representable range
 };
 
 __device__ __forceinline__ long long wave_incl_scan(long long v) {
@@ -75,13 +88,30 @@ __device__ __forceinline__ long long wave_incl_scan(long long v) {
   return v;
 }
 
-// block-local sums of 4096 samples
+// 8 consecutive samples of a 16-byte aligned group (d_s comes from hipMalloc, groups start at multiples of 8)
+__device__ __forceinline__ void load8(const int16_t *__restrict__ s, long long base, int n, int (&x)[8]) {
+  if (base + 8 <= n) {
+    const uint4 w = *reinterpret_cast<const uint4 *>(s + base);
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[2 * k] = (int)(short)(u[k] & 0xffffu); x[2 * k + 1] = (int)(short)(u[k] >> 16); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = (base + k < n) ? (int)s[base + k] : 0;
+  }
+}
+
+// block-local sums of 4096 samples (16-byte loads, lane-contiguous)
 __global__ __launch_bounds__(256) void k_scan_partial(const int16_t *__restrict__ s, int n,
                                                       long long *__restrict__ blk) {
-  long long base = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
   long long acc = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) if (base + k < n) acc += s[base + k];
+  for (int r = 0; r < 2; r++) {
+    int x[8];
+    load8(s, (long long)blockIdx.x * SCAN_BLOCK + r * 2048 + threadIdx.x * 8, n, x);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc += x[k];
+  }
   acc = wave_incl_scan(acc);
   __shared__ long long ws[4];
   if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = acc;
@@ -107,26 +137,54 @@ __global__ __launch_bounds__(256) void k_scan_blocks(long long *blk, int nblk) {
     __syncthreads();
   }
 }
-// P[0] = 0, P[i+1] = sum(s[0..i])
+// P[0] = 0, P[i+1] = sum(s[0..i]).  Two rounds of 2048 samples: thread t scans its 8 consecutive samples (one 16-byte
+// load), a wave scan and four wave totals give the offsets, and the 2048 prefix values go through LDS (k-major,
+// padded rows) so that every global store instruction of a wave writes 512 contiguous bytes.
 __global__ __launch_bounds__(256) void k_scan_final(const int16_t *__restrict__ s, int n,
                                                     const long long *__restrict__ blk,
                                                     long long *__restrict__ P) {
-  long long base = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-  long long v[SCAN_PER_THREAD], acc = 0;
+  __shared__ long long sh[8 * SCAN_ROW];
+  __shared__ long long ws[2][4];
+  const int t = threadIdx.x;
+  long long carry = blk[blockIdx.x];
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) { acc += (base + k < n) ? s[base + k] : 0; v[k] = acc; }
-  long long inc = wave_incl_scan(acc);
-  __shared__ long long ws[4];
-  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  long long off = blk[blockIdx.x] + inc - acc;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += ws[w];
+  for (int r = 0; r < 2; r++) {
+    const long long base = (long long)blockIdx.x * SCAN_BLOCK + r * 2048;
+    int x[8];
+    load8(s, base + t * 8, n, x);
+    long long v[8], acc = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) if (base + k < n) P[base + k + 1] = off + v[k];
-  if (blockIdx.x == 0 && threadIdx.x == 0) P[0] = 0;
+    for (int k = 0; k < 8; k++) { acc += x[k]; v[k] = acc; }
+    const long long inc = wave_incl_scan(acc);
+    if ((t & 63) == 63) ws[r][t >> 6] = inc;
+    __syncthreads();                                   // also: the previous round's image has been read
+    long long off = carry + inc - acc;
+    for (int w = 0; w < (t >> 6); w++) off += ws[r][w];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[k * SCAN_ROW + t] = off + v[k];
+    carry += ws[r][0] + ws[r][1] + ws[r][2] + ws[r][3];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int e = j * 256 + t;                       // element e of the round = thread e >> 3, slot e & 7
+      if (base + e < n) P[base + e + 1] = sh[(e & 7) * SCAN_ROW + (e >> 3)];
+    }
+  }
+  if (blockIdx.x == 0 && t == 0) P[0] = 0;
 }
 
-// symdemod.c:260-335: thread t = timing offset, sequential over symbols
+// the window buffer after memmove(samples, samples + slide, keep) (symdemod.c:101-112): everything beyond `keep` stays
+// what it was.  Ping-pong: out becomes the new buffer.
+__global__ __launch_bounds__(256) void k_slide(const int16_t *__restrict__ in, int16_t *__restrict__ out, int slide, int keep, int cap) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < cap; i += (long long)gridDim.x * 256)
+    out[i] = i < keep ? in[i + slide] : in[i];
+}
+
+// symdemod.c:260-335: thread t = timing offset; the energy is accumulated symbol by symbol IN ORDER in double, as the
+// reference's loop does (this is the form that stays exact when sums leave the 2^53 range).  The integrator sums of
+// TS_BATCH symbols are formed first -- their prefix reads are independent, so their latencies overlap -- and then added
+// in order: 460 -> ~100 us per window at 10 MS/s (9 760 offsets x 1 024 symbols).
+#define TS_BATCH 16
 __global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__ P, int lo,
                                                    const int *__restrict__ sw, int symbolclocks,
                                                    int nsymbols, int noff, double *__restrict__ energies) {
@@ -134,8 +192,23 @@ __global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__
   if (t >= noff) return;
   const long long *Pb = P + lo + t;
   double energy = 0;
-  int k = 0;
-  for (int i = 0; i < nsymbols; i++) {
+  int i = 0;
+  if (symbolclocks == 1) {
+    for (; i + TS_BATCH <= nsymbols; i += TS_BATCH) {
+      long long sy[TS_BATCH];
+      long long a = Pb[sw[2 * i]];
+#pragma unroll
+      for (int u = 0; u < TS_BATCH; u++) {
+        const long long b = Pb[sw[2 * (i + u) + 1]], c = Pb[sw[2 * (i + u) + 2]];
+        sy[u] = -(b - a) + (c - b);
+        a = c;
+      }
+#pragma unroll
+      for (int u = 0; u < TS_BATCH; u++) energy += (double)(sy[u] * sy[u]);
+    }
+  }
+  int k = 2 * i * symbolclocks;
+  for (; i < nsymbols; i++) {
     long long sym = 0;
     for (int j = 0; j < symbolclocks; j++, k += 2) {
       long long a = Pb[sw[k]], b = Pb[sw[k + 1]], c = Pb[sw[k + 2]];
@@ -245,7 +318,8 @@ extern "C" void *symd_create(int max_samples) {
   h->cap = max_samples > 0 ? max_samples : 1;
   CHK(hipSetDevice(h->dev));
   CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
-  CHK(hipMalloc(&h->d_s, sizeof(int16_t) * (size_t)h->cap));
+  CHK(hipMalloc(&h->d_s, sizeof(int16_t) * ((size_t)h->cap + 8)));
+  CHK(hipMemsetAsync(h->d_s, 0, sizeof(int16_t) * ((size_t)h->cap + 8), h->st));     // the reference's buffer comes from calloc-like use: see store ops
   CHK(hipMalloc(&h->d_P, sizeof(long long) * ((size_t)h->cap + 1)));
   h->nblk_cap = (h->cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
   CHK(hipMalloc(&h->d_blk, sizeof(long long) * (size_t)h->nblk_cap));
@@ -260,16 +334,56 @@ extern "C" void symd_destroy(void *p) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
-  (void)hipFree(h->d_s); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
-  (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym); (void)hipFree(h->d_part); (void)hipFree(h->d_flag);
+  (void)hipFree(h->d_s); (void)hipFree(h->d_s2); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
+  (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym); (void)hipFree(h->d_part); (void)hipFree(h->d_terms);
+  (void)hipFree(h->d_flag);
   free(h);
 }
-extern "C" int symd_load(void *p, const int16_t *samples, int n, int is_dev) {
+// ---- the window buffer kept in HBM (symdemod.c:96-125 without the host copy) ----
+extern "C" int symd_store_reset(void *p) {
   Symd *h = (Symd *)p;
-  if (!h || n < 0 || n > h->cap) { snprintf(g_err, sizeof g_err, "symd_load: bad size %d (cap %d)", n, h ? h->cap : 0); return -1; }
+  if (!h) return -1;
   CHK(hipSetDevice(h->dev));
-  CHK(hipMemcpyAsync(h->d_s, samples, sizeof(int16_t) * (size_t)n,
-                     is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->st));
+  CHK(hipMemsetAsync(h->d_s, 0, sizeof(int16_t) * ((size_t)h->cap + 8), h->st));
+  h->n = 0; h->inexact_last = 0;
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int symd_store_put(void *p, int at, const int16_t *src, int n, int src_is_dev) {
+  Symd *h = (Symd *)p;
+  if (!h || at < 0 || n < 0 || (long long)at + n > h->cap) {
+    snprintf(g_err, sizeof g_err, "symd_store_put: [%d, %d) outside the buffer of %d samples", at, at + n, h ? h->cap : 0);
+    return -1;
+  }
+  if (n == 0) return 0;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipMemcpyAsync(h->d_s + at, src, sizeof(int16_t) * (size_t)n, src_is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->st));
+  if (src_is_dev) CHK(hipStreamSynchronize(h->st));         // the producer may recycle its block as soon as this returns
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int symd_store_slide(void *p, int slide, int nsamples) {
+  Symd *h = (Symd *)p;
+  if (!h || slide < 0 || nsamples < slide || nsamples > h->cap) { snprintf(g_err, sizeof g_err, "symd_store_slide: bad arguments"); return -1; }
+  if (slide == 0) return 0;
+  CHK(hipSetDevice(h->dev));
+  if (!h->d_s2) CHK(hipMalloc(&h->d_s2, sizeof(int16_t) * ((size_t)h->cap + 8)));
+  {
+    int nb = (h->cap + 255) / 256; if (nb > 4096) nb = 4096;
+    k_slide<<<nb, 256, 0, h->st>>>(h->d_s, h->d_s2, slide, nsamples - slide, h->cap);
+    CHK(hipGetLastError());
+    int16_t *t = h->d_s; h->d_s = h->d_s2; h->d_s2 = t;
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int symd_store_scan(void *p, int n) {
+  Symd *h = (Symd *)p;
+  if (!h || n < 0 || n > h->cap) { snprintf(g_err, sizeof g_err, "symd_store_scan: bad size %d (cap %d)", n, h ? h->cap : 0); return -1; }
+  CHK(hipSetDevice(h->dev));
   h->n = n;
   if (n > 0) {
     int nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -281,6 +395,12 @@ extern "C" int symd_load(void *p, const int16_t *samples, int n, int is_dev) {
   return 0;
 fail:
   return -1;
+}
+extern "C" int symd_load(void *p, const int16_t *samples, int n, int is_dev) {
+  Symd *h = (Symd *)p;
+  if (!h || n < 0 || n > h->cap) { snprintf(g_err, sizeof g_err, "symd_load: bad size %d (cap %d)", n, h ? h->cap : 0); return -1; }
+  if (symd_store_put(p, 0, samples, n, is_dev) != 0) return -1;
+  return symd_store_scan(p, n);
 }
 extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks, int nsymbols, int noff,
                                double *energies) {
@@ -301,7 +421,9 @@ extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks,
     CHK(hipMemcpyAsync(h->d_idx, sw, sizeof(int) * (size_t)nsw, hipMemcpyHostToDevice, h->st));
     const int nslices = (nsymbols + TS_SLICE - 1) / TS_SLICE;
     unsigned flag = 1;
-    if (!getenv("ISEE3DSP_SEQUENTIAL") && grow(&h->d_part, &h->part_cap, sizeof(unsigned long long) * (size_t)nslices * (size_t)noff) == 0) {
+    // the exact-integer parallel form first -- unless the previous window already left its range (it then will again:
+    // at 10 MS/s one symbol spans 9 760 samples and the window total passes 2^53)
+    if (!getenv("ISEE3DSP_SEQUENTIAL") && !h->inexact_last && grow(&h->d_part, &h->part_cap, sizeof(unsigned long long) * (size_t)nslices * (size_t)noff) == 0) {
       CHK(hipMemsetAsync(h->d_flag, 0, sizeof(unsigned), h->st));
       k_timesearch_part<<<dim3((noff + 255) / 256, nslices), 256, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks,
                                                                             nsymbols, noff, (unsigned long long *)h->d_part, h->d_flag);
@@ -311,7 +433,10 @@ extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks,
       CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
       CHK(hipStreamSynchronize(h->st));
     }
-    if (flag) {     // some sum left the exactly-representable range: redo in the reference's own order
+    // remember it for the next windows, and look again every 32nd (a capture may change level)
+    h->inexact_last = flag ? (h->inexact_last % 32) + 1 : 0;
+    if (h->inexact_last == 32 || getenv("ISEE3DSP_RETRY_EXACT")) h->inexact_last = 0;
+    if (flag) {     // some sum left the exactly-representable range: the reference's own order of additions
       k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks, nsymbols,
                                                        noff, (double *)h->d_e);
       CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));

@@ -518,6 +518,8 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   HIPCHK(hipMalloc(&v->m[0], sizeof(uint16_t) * V224_NSTATES));
   HIPCHK(hipMalloc(&v->m[1], sizeof(uint16_t) * V224_NSTATES));
   HIPCHK(hipMalloc(&v->rows, (size_t)len * V224_ROWWORDS * sizeof(uint32_t)));
+  // (the reference mallocs its ring, port.c:58: rows never written are undefined there; here they read as zero)
+  HIPCHK(hipMemsetAsync(v->rows, 0, (size_t)len * V224_ROWWORDS * sizeof(uint32_t), v->st));
   HIPCHK(hipMalloc(&v->rowmeta, (size_t)len * sizeof(uint32_t)));
   HIPCHK(hipMemsetAsync(v->rowmeta, 0, (size_t)len * sizeof(uint32_t), v->st));
   HIPCHK(hipMalloc(&v->ds, sizeof(V224Dev)));

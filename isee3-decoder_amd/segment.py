@@ -17,12 +17,17 @@ import numpy as np
 
 
 def plan_segments(nblocks, nseg, warm_blocks):
-    """[(first block incl. warm-up, first own block, end block)] for nseg near-equal block-aligned segments."""
+    """[(first block incl. warm-up, first own block, end block)] for nseg near-equal block-aligned segments.  Segments
+    whose warm-up would reach back to block 0 all decode the capture from its first sample; they are merged into ONE
+    first segment (decoding the same start several times buys nothing), so fewer than nseg entries may come back."""
     edges = [round(i * nblocks / nseg) for i in range(nseg + 1)]
-    return [(max(0, edges[i] - warm_blocks), edges[i], edges[i + 1]) for i in range(nseg) if edges[i + 1] > edges[i]]
+    segs = [(max(0, edges[i] - warm_blocks), edges[i], edges[i + 1]) for i in range(nseg) if edges[i + 1] > edges[i]]
+    first = [s for s in segs if s[0] == 0]
+    rest = [s for s in segs if s[0] > 0]
+    return ([(0, 0, first[-1][2])] if first else []) + rest
 
 
-def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=400, settled=2300, from_start=None):
+def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=400, settled=2300, end_guard=64):
     """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments;
     overlap_bits[i]: how many decoded bits lie between the start of part i+1 and the cut (its warm-up region).
     A probe is taken from the settled end of that region and located in the previous part -- but only where it
@@ -31,21 +36,13 @@ def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=4
     occur exactly ONCE in that range (repetitive telemetry can match one frame off), and with that alignment the two
     parts must agree on EVERYTHING they share from up to `verify_back` bits before the probe (not before the part's
     `settled` bit) to the end of part i; otherwise the seam counts as unmatched.
-    from_start[i] (optional): part i+1 begins at the very first sample of the capture (its warm-up was clipped there), so
-    it decodes the same samples as the parts before it from bit 0 on: everything joined so far must be a prefix of it.
+    end_guard: the last bits of a part are not compared -- its final symdemod window ran into the end of the input
+    (symdemod.c reads whatever its buffer holds there), so they may differ from a decode that had the samples.
     Returns (joined bits, seams matched, seams total)."""
     out = parts[0]
     ok = 0
     for i, (nxt, ovl) in enumerate(zip(parts[1:], overlap_bits)):
         placed = False
-        if from_start is not None and from_start[i]:
-            if len(nxt) >= len(out) and nxt.startswith(out):
-                out, placed = nxt, True
-            if placed:
-                ok += 1
-            else:
-                out = out + nxt
-            continue
         # the first ~2300 bits of a restarted decode are unreliable: start-up delay, and vdecode decides its
         # symbol-pair phase only once per 2048 ODD symbols = two frames (vdecode.c:122-139).  Probe between
         # there and the end of the overlap.
@@ -60,7 +57,8 @@ def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=4
             if p < 0 or out.find(probe, p + 1, hi) >= 0:
                 continue                                 # absent, or ambiguous inside the window
             back = max(0, min(verify_back, w - settled, p))
-            if out[p - back:] != nxt[w - back:w - back + (len(out) - p + back)]:
+            share = max(probe_len + back, len(out) - end_guard - (p - back))
+            if out[p - back:p - back + share] != nxt[w - back:w - back + share]:
                 continue                                 # the alignment does not hold over the rest of the overlap
             out = out[:p] + nxt[w:]
             placed = True
@@ -109,6 +107,6 @@ def decode_segmented(iq, samprate, binsize, nseg, run_chain, warm_blocks=7, conc
         raise errors[0]
     bps = (1024.545058 / 2 if symrate in (None, "1024") else float(symrate) / 2)
     overlaps = [int((plan[i + 1][1] - plan[i + 1][0]) * N / samprate * bps) for i in range(len(plan) - 1)]
-    bits, ok, seams = stitch(parts, overlaps, from_start=[plan[i + 1][0] == 0 for i in range(len(plan) - 1)])
+    bits, ok, seams = stitch(parts, overlaps)
     processed = sum((b1 - b0) * N for b0, _, b1 in plan)
     return bits, ok, seams, processed

@@ -7,7 +7,7 @@
 #include "../../isee3-decoder_amd/cli/symdemod_core.h"
 
 typedef struct { int16_t *s; int n, cap; } cpu_t;
-static void *c_create(int cap) { cpu_t *c = calloc(1, sizeof *c); c->s = malloc(sizeof(int16_t) * (size_t)cap); c->cap = cap; return c; }
+static void *c_create(int cap) { cpu_t *c = calloc(1, sizeof *c); c->s = calloc((size_t)cap, sizeof(int16_t)); c->cap = cap; return c; }
 static int c_load(void *h, const int16_t *s, int n) { cpu_t *c = h; memcpy(c->s, s, sizeof(int16_t) * (size_t)n); c->n = n; return 0; }
 static long long seg(const cpu_t *c, int a, int b) { long long v = 0; for (int i = a; i < b; i++) v += c->s[i]; return v; }
 static int c_ts(void *h, int lo, const int *sw, int sc, int ns, int noff, double *en) {
@@ -36,10 +36,27 @@ static int c_demod(void *h, const int *ed, int sc, int ns, double gain, uint8_t 
   return 0;
 }
 static void c_destroy(void *h) { cpu_t *c = h; free(c->s); free(c); }
+/* the engine-resident window buffer (symdemod_run_blk): plain memmove / memcpy on the CPU engine's own copy */
+static int c_slide(void *h, int slide, int n) { cpu_t *c = h; memmove(c->s, c->s + slide, sizeof(int16_t) * (size_t)(n - slide)); return 0; }
+static int c_put(void *h, int at, const int16_t *src, int n, int dev) { cpu_t *c = h; (void)dev; if (at + n > c->cap) return -1; memcpy(c->s + at, src, sizeof(int16_t) * (size_t)n); return 0; }
+static int c_scan(void *h, int n) { cpu_t *c = h; c->n = n; return 0; }
+/* block views of stdin in pieces of an awkward size */
+static int16_t g_blk[7919];
+static long blk_next(void *ctx, const int16_t **blk, int *is_dev, long max) {
+  (void)ctx;
+  long want = max < 7919 ? max : 7919, got = 0;
+  while (got < want * 2) { long k = (long)fread((char *)g_blk + got, 1, (size_t)(want * 2 - got), stdin); if (k <= 0) break; got += k; }
+  *blk = g_blk; *is_dev = 0;
+  return got / 2;
+}
 
 int main(int argc, char **argv) {
   symdemod_opts o;
   symdemod_parse_args(&o, argc, argv);
+  if (getenv("SYMD_STORE") && atoi(getenv("SYMD_STORE"))) {
+    symdemod_engine e = { c_create, c_load, c_ts, c_demod, c_destroy, c_slide, c_put, c_scan };
+    return symdemod_run_blk(&o, &e, blk_next, NULL, stdout, stderr) ? 2 : 0;
+  }
   symdemod_engine e = { c_create, c_load, c_ts, c_demod, c_destroy };
   return symdemod_run(&o, &e, 0, stdout, stderr) ? 2 : 0;
 }

@@ -65,13 +65,28 @@ def test_stitch_locates_the_seam_by_position_and_verifies_it():
         bad[i] ^= 1
     out, ok, tot = segment.stitch([p0, bytes(bad)], [ovl])
     assert ok == 0 and len(out) == len(p0) + len(bad)
-    # segments whose warm-up was clipped at the start of the capture decode the same samples from bit 0
-    out, ok, tot = segment.stitch([full[:300], full[:900], full[:1500]], [512, 1024], from_start=[True, True])
-    assert (ok, tot) == (2, 2) and out == full[:1500]
-    out, ok, tot = segment.stitch([full[:300], full[1:900]], [512], from_start=[True])
-    assert ok == 0
     # periodic frames: alignment is decided by position, never a frame off
     frame = bytes(rng.integers(48, 50, 1024, dtype=np.uint8))
     per = frame * 24
     out, ok, tot = segment.stitch([per[:9000 - 300], per[9000 - ovl:20000]], [ovl])
     assert ok == 1 and out == per[:20000]
+
+
+def test_two_rank_gloo_segmented_chain_path():
+    """bench.py --workload chain --chain-segments S on two ranks, without a GPU: the same plan / shard / run_segments /
+    all_gather_object / stitch code with a stand-in for run_chain.  Every seam must verify and the stitched stream must
+    be the one stream the segments were cut from; the line carries ranks_seen and the per-rank times."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "tests", "_dist_worker_chain.py"), "16", "64"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    assert r["world"] == 2 and r["ranks_seen"] == 2 and len(r["per_rank_ms"]) == 2
+    # 16 segments of 4 blocks, warm-up 7 blocks: the first two start at block 0 and are merged
+    assert r["segments"] == 15 and r["seams"] == {"matched": 14, "total": 14}
+    assert r["equal_to_truth"] and r["nbits"] > 30000
+    assert r["mine"] == list(range(0, 15, 2)) and r["calls_rank0"] == 8

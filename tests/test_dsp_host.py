@@ -48,12 +48,16 @@ def sym_input(z, name):
     return bb
 
 
+@pytest.mark.parametrize("store", ["0", "1"], ids=["host_buffer", "engine_store"])
 @pytest.mark.parametrize("name", [str(n) for n in np.load(SG)["names"]])
-def test_symdemod_host_logic_vs_reference_stdout(sym_harness, name):
+def test_symdemod_host_logic_vs_reference_stdout(sym_harness, name, store):
+    """the window loop with its sample buffer on the host (stand-alone stage: bytes from read()) and with the buffer kept
+    inside the engine (the in-process chain: block views, store_slide / store_put / store_scan): the reference's stdout"""
     z = np.load(SG)
     bb = sym_input(z, name)
     p = subprocess.run([sym_harness] + [str(a) for a in z[name + "/args"]], input=bb.tobytes(),
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600,
+                       env=dict(os.environ, SYMD_STORE=store))
     assert p.stdout == z[name + "/stdout"].tobytes()
 
 

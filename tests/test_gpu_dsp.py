@@ -279,6 +279,8 @@ def test_segmented_decode_matches_single_pass(pkg):
     assert n > 18000 and bits[:n - 64] == single[:n - 64]
     # planning: block-aligned, covering, warm-up clipped at the start
     assert seg.plan_segments(24, 4, 3) == [(0, 0, 6), (3, 6, 12), (9, 12, 18), (15, 18, 24)]
+    # segments whose warm-up reaches back to block 0 are merged into the first one
+    assert seg.plan_segments(8, 8, 3) == [(0, 0, 4), (1, 4, 5), (2, 5, 6), (3, 6, 7), (4, 7, 8)]
 
 
 def test_vdecode_cli_file_input_uses_both_decoders_same_output(pkg, tmp_path):
@@ -353,7 +355,7 @@ def test_config2_full_size_chain_equals_oracle_chain(pkg):
 
 def test_config4_form_64_overlapped_segments(pkg):
     """BASELINE configs[4] form at a shortened capture: ONE capture cut into 64 block-aligned segments, each extended to
-    the left by a 7-block warm-up, decoded independently (two chains at a time on this GPU) and stitched: all 63 seams
+    the left by a 7-block warm-up, decoded independently (two chains at a time on this GPU) and stitched: all seams
     verified, result == the single-pass decode of the same capture."""
     from importlib import import_module
     seg = import_module("isee3_decoder_amd.segment")
@@ -361,7 +363,90 @@ def test_config4_form_64_overlapped_segments(pkg):
     iq, sent = orc.gen_iq(97, fs, 64.5, fc_hz=-2222.2, amp=3000.0, cn0_dbhz=50.0)
     single = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
     bits, ok, seams, processed = seg.decode_segmented(iq, fs, 1.0, 64, pkg.run_chain, warm_blocks=7, concurrency=2)
-    assert seams == 63 and ok == 63
+    # 64 one-block segments; the eight whose 7-block warm-up reaches back to the start of the capture are one segment
+    assert seams == 56 and ok == 56
     n = min(len(bits), len(single))
     assert n > 30000 and bits[:n - 64] == single[:n - 64]
-    assert processed > 7 * 64 * 16384 * 0.8                    # every segment really carried its warm-up
+    assert processed == (8 + 56 * 8) * 16384                  # every later segment really carried its warm-up
+
+
+def test_symd_window_store_in_hbm(pkg):
+    """symd_store_slide / _put / _scan == memmove / memcpy / prefix sums on a host copy of the buffer (symdemod.c:96-125),
+    stale tail included; sources in host and in device memory; sizes that are not multiples of the scan tile."""
+    rng = np.random.default_rng(77)
+    cap = 3 * 4096 + 1234
+    eng = pkg.SymDemodEngine(cap)
+    host = np.zeros(cap, np.int16)
+    n = 0
+    first = True
+    for slide, add, dev in ((0, 5000, False), (1200, 4321, True), (7000, 6000, False), (3, 1, True), (0, cap, False)):
+        if slide:
+            eng.store_slide(slide, n)
+            host[:n - slide] = host[slide:n].copy()
+            n -= slide
+        add = min(add, cap - n)
+        blk = rng.integers(-32768, 32768, add, dtype=np.int16)
+        eng.store_put(n, pkg.DeviceBuffer.from_numpy(blk) if dev else blk)
+        host[n:n + add] = blk
+        n += add
+        eng.store_scan(cap)                              # the whole buffer, stale tail included
+        # check through the integrate-and-dump of one 'symbol' per probe: demod returns exact integer sums
+        edges = np.array([0, cap // 3, cap], np.int32)
+        _, e = eng.demod(edges, 1, 1, 0.0)
+        want = -int(host[:cap // 3].astype(np.int64).sum()) + int(host[cap // 3:].astype(np.int64).sum())
+        assert e == float(want) ** 2
+        for a, b, c in ((1, 2, 3), (4095, 4096, 4097), (n - 2, n - 1, n), (0, n // 2, cap)):
+            _, e = eng.demod(np.array([a, b, c], np.int32), 1, 1, 0.0)
+            want = -int(host[a:b].astype(np.int64).sum()) + int(host[b:c].astype(np.int64).sum())
+            assert e == float(want) ** 2
+    eng.close()
+
+
+def test_chain_on_a_capture_in_device_memory(pkg):
+    """isee3_chain_run_dev (capture already in HBM) == isee3_chain_run_mem (capture in host memory) == the oracle chain;
+    per-stage engine times are reported"""
+    fs = 32768.0
+    iq, _ = orc.gen_iq(4310, fs, 9.0, fc_hz=-777.7, amp=3000.0, cn0_dbhz=50.0)
+    ms = []
+    host = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
+    dev = pkg.run_chain(pkg.DeviceBuffer.from_numpy(iq), samprate=fs, binsize=1.0, symrate="1024", stage_ms=ms)
+    assert dev == host and len(ms) == 3 and all(m > 0 for m in ms)
+    bb, _, _, _ = orc.pmdemod(iq, samprate=fs, binsize=1.0, want_pre=False)
+    sy, _, _ = orc.symdemod(bb, samprate=int(fs), c_opt="1024")
+    want, _ = orc.vdecode(sy)
+    assert dev == want and len(want) > 4000
+
+
+def test_timesearch_beyond_2_pow_53_takes_the_ordered_path(pkg, monkeypatch):
+    """10 MS/s shape: one symbol spans ~9 760 samples, the window's energy passes 2^53 and the exact-integer parallel sum no
+    longer equals the reference's ordered double accumulation: the engine must fall back to the ordered kernel (first
+    window) and go there directly afterwards (later windows), with the oracle's energies every time."""
+    fs = 10_000_000
+    bb, _ = orc.gen_baseband(61, float(fs), 0.45, amp=9000.0, noise_sigma=6000.0)
+    ss = fs / 1024.545058
+    nsym, first = 200, int(ss / 2)
+    half = 0.5 * ss
+    sw, sc = [0], half
+    for _ in range(2 * nsym):
+        sw.append(int(np.rint(sc))); sc += half
+    sw = np.array(sw, np.int32)
+    first_off = int(-ss / 2)
+    noff = len([o for o in range(first_off, int(np.ceil(ss / 2))) if o < ss / 2])
+    eng = pkg.SymDemodEngine(len(bb))
+    eng.load(bb)
+    lo = first + first_off
+    # oracle energies for a few offsets: ordered double accumulation of (double)(sym*sym)
+    P = np.concatenate([[0], np.cumsum(bb.astype(np.int64))])
+    def ordered(t):
+        e = 0.0
+        for i in range(nsym):
+            a, b, c = P[lo + t + sw[2 * i]], P[lo + t + sw[2 * i + 1]], P[lo + t + sw[2 * i + 2]]
+            s = int(-(b - a) + (c - b))
+            e += float(s * s)
+        return e
+    for _ in range(3):
+        en = eng.timesearch(lo, sw, 1, nsym, noff)
+        for t in (0, 1, noff // 2, noff - 1):
+            assert en[t] == ordered(t)
+    assert en.max() >= 2.0 ** 53
+    eng.close()
