@@ -279,7 +279,7 @@ def main():
     ap.add_argument("--chain-rate", type=float, default=250000.0)
     ap.add_argument("--chain-bin", type=float, default=1.0)
     ap.add_argument("--chain-steps", type=int, default=0, help="timed chain steps in the default run (0: as --steps)")
-    ap.add_argument("--chain-cpu-seconds", type=float, default=6.0, help="seconds of capture given to the CPU chain baseline")
+    ap.add_argument("--chain-cpu-seconds", type=float, default=21.0, help="seconds of capture given to the CPU chain baseline")
     ap.add_argument("--chain-segments", type=int, default=1,
                     help="> 1: cut ONE capture into this many overlapped segments over all ranks (configs[4])")
     ap.add_argument("--chain-warm-blocks", type=int, default=7)

@@ -493,8 +493,11 @@ fail:
 struct Pmd {
   int dev; hipStream_t st;
   int N, logN;
-  double2 *buf, *spec, *tmp, *tw, *lo;   // lo = optional de-chirp table (conj applied at load)
-  int16_t *d_iq;
+  double2 *buf, *spec, *tmp, *tw, *lo;   // buf / tw: only for N < 2^12 (register-radix path); lo = optional de-chirp table
+  double2 *twA, *twB, *twR;              // LDS-pass path: W_N^(4096 h), W_N^l (l < 4096), W_256^m
+  int16_t *d_iq;                         // staging for host blocks
+  const int16_t *cur_iq; int cur_flip;   // the block pmd_load announced (device memory): read by the FFT's first pass,
+                                         // by the spin-down sum and by the output kernel -- no double-precision copy of it exists
   void *d_red; size_t red_cap;           // reduction scratch
   int16_t *d_out16; double *d_pre;
   int have_lo;
@@ -594,6 +597,112 @@ __global__ __launch_bounds__(256) void k_fft_radix(const double2 *__restrict__ x
   }
 }
 
+// ---- LDS-staged passes (N >= 2^12) ---------------------------------------------------------------------------------
+// One launch = one Stockham stage of radix R = R1 * R2 (32 .. 256), i.e. 5 .. 8 of the log2 N butterfly levels per trip
+// through HBM: 2^23 points take 3 launches (8 + 8 + 7 levels, 3 x 256 MiB of traffic) instead of 6, 2^18 points 3 (6 + 6 + 6),
+// 2^16 points 2.  A workgroup owns a tile of FT = 16 consecutive columns t (thread index = column + 16 * row part), so
+// every global access is a run of 16 consecutive double2 = 256 bytes:
+//   step 1  thread (c, a): loads x[t + (a + R2 b) N/R], b < R1, does the R1-point DFT over b in registers, multiplies by
+//           W_R^(a k1) and parks the results in LDS as Z[a][k1][c];
+//   step 2  thread (c, k1): pulls Z[.][k1][c], does the R2-point DFT over a: X[k1 + R1 k2]; multiplies by the stage
+//           twiddle W_N^(p s k) (two-level table: W_N^(4096 h) * W_N^l) and stores y[q + R p s + k s].
+// In the first stage (s = 1) a tile's output is ONE contiguous block of 16 R elements; later stages write 256-byte runs.
+// The first stage reads the int16 (I, Q) pairs themselves (pmdemod.c:209-229, de-chirp :237-243 included): the block is
+// never expanded to doubles in memory.
+#define FT 16
+template <int R> __device__ __forceinline__ void dft_regs(double2 (&a)[R]) {     // radix-2 DIF network; a[brev(k)] = X[k]
+#pragma unroll
+  for (int span = R / 2; span >= 1; span >>= 1) {
+#pragma unroll
+    for (int base = 0; base < R; base += 2 * span) {
+#pragma unroll
+      for (int m = 0; m < span; m++) {
+        const double2 u = a[base + m], v = a[base + m + span];
+        a[base + m] = make_double2(u.x + v.x, u.y + v.y);
+        const double dr = u.x - v.x, di = u.y - v.y;
+        const int e = m * (8 / span);                    // exponent of omega_16
+        if (e == 0) a[base + m + span] = make_double2(dr, di);
+        else if (e == 4) a[base + m + span] = make_double2(di, -dr);          // * (-j)
+        else { const double c = k_c16[e], sn = k_s16[e];
+               a[base + m + span] = make_double2(dr * c + di * sn, di * c - dr * sn); }   // * (c - j sn)
+      }
+    }
+  }
+}
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// sample i of the block as pmdemod.c:209-229 forms it (+ :237-243 with a de-chirp table)
+__device__ __forceinline__ double2 iq_sample(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int i, int flip) {
+  const short2 v = iq[i];
+  double x = flip ? (double)v.y : (double)v.x, y = flip ? (double)v.x : (double)v.y;
+  if (lo) {                                // buffer[i] *= conj(lophase)
+    const double pr = lo[i].x, pi = -lo[i].y;
+    const double nx = x * pr - y * pi, ny = x * pi + y * pr;
+    x = nx; y = ny;
+  }
+  return make_double2(x, y);
+}
+template <int LG> struct PassShape;
+template <> struct PassShape<5> { static constexpr int R1 = 8,  R2 = 4; };
+template <> struct PassShape<6> { static constexpr int R1 = 8,  R2 = 8; };
+template <> struct PassShape<7> { static constexpr int R1 = 16, R2 = 8; };
+template <> struct PassShape<8> { static constexpr int R1 = 16, R2 = 16; };
+constexpr int lg2c(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
+
+template <int LG, bool FROM_IQ>
+__global__ __launch_bounds__(FT * (PassShape<LG>::R1 > PassShape<LG>::R2 ? PassShape<LG>::R1 : PassShape<LG>::R2))
+void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip,
+                double2 *__restrict__ y, const double2 *__restrict__ twA, const double2 *__restrict__ twB,
+                const double2 *__restrict__ twR, int N, int s) {
+  constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2;
+  extern __shared__ double2 Z[];                          // [R2][R1][FT]
+  const int c = threadIdx.x & (FT - 1), r = threadIdx.x >> 4;
+  const int t = blockIdx.x * FT + c, stride = N / R;
+  if (r < R2) {                                           // ---- step 1, thread (c, a = r)
+    double2 v[R1];
+#pragma unroll
+    for (int b = 0; b < R1; b++) {
+      const int i = t + (r + R2 * b) * stride;
+      if constexpr (FROM_IQ) v[b] = iq_sample(iq, lo, i, flip); else v[b] = x[i];
+    }
+    dft_regs<R1>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; k1++) {
+      double2 val = v[brev(k1, lg2c(R1))];
+      if (k1 > 0) val = cmul(val, twR[(r * k1) * (256 / R)]);      // W_R^(a k1); a = 0 reads W^0 = 1 exactly
+      Z[(r * R1 + k1) * FT + c] = val;
+    }
+  }
+  __syncthreads();
+  if (r < R1) {                                           // ---- step 2, thread (c, k1 = r)
+    double2 u[R2];
+#pragma unroll
+    for (int a = 0; a < R2; a++) u[a] = Z[(a * R1 + r) * FT + c];
+    dft_regs<R2>(u);
+    const int q = t & (s - 1), ps = t - q;
+    double2 *__restrict__ out = y + q + (size_t)R * ps;
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) {
+      const int k = r + R1 * k2;
+      double2 val = u[brev(k2, lg2c(R2))];
+      if (ps != 0 && k != 0) {                            // stage twiddle W_N^(ps k), ps k < N
+        const unsigned idx = (unsigned)ps * (unsigned)k;
+        double2 w = twB[idx & 4095u];
+        if (idx >> 12) w = cmul(twA[idx >> 12], w);
+        val = cmul(val, w);
+      }
+      out[(size_t)k * s] = val;
+    }
+  }
+}
+// W_N^(4096 h) for h < N / 4096, W_N^l for l < min(N, 4096), W_256^m
+__global__ __launch_bounds__(256) void k_twiddles2(double2 *twA, double2 *twB, double2 *twR, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double sn, cs;
+  if (i < N / 4096) { sincospi(-2.0 * (double)i * 4096.0 / (double)N, &sn, &cs); twA[i] = make_double2(cs, sn); }
+  if (i < 4096 && i < N) { sincospi(-2.0 * (double)i / (double)N, &sn, &cs); twB[i] = make_double2(cs, sn); }
+  if (i < 256) { sincospi(-2.0 * (double)i / 256.0, &sn, &cs); twR[i] = make_double2(cs, sn); }
+}
+
 struct PeakRec { double e; int idx; int pad; };
 __device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) {
   return e > be || (e == be && i > bi);     // ">=" while scanning upward == last maximum wins
@@ -654,14 +763,15 @@ __device__ __forceinline__ double2 carrier_at(unsigned long long i, unsigned lon
 }
 
 #define RED_BLOCKS 1024
-// pass 1: buf[i] *= carrier_i, partial sums of the result
-__global__ __launch_bounds__(256) void k_mix(double2 *__restrict__ buf, int N, unsigned long long u_hi,
-                                             unsigned long long u_lo, double logrho, double2 *__restrict__ part) {
+// pass 1 (pmdemod.c:328-336): sum of sample_i * carrier_i.  The samples are re-formed from the int16 block and the products
+// are not stored: pass 2 forms them again (same operations, same bits) -- 4 B instead of 2 x 16 B of traffic per sample.
+__global__ __launch_bounds__(256) void k_mix(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
+                                             unsigned long long u_hi, unsigned long long u_lo, double logrho,
+                                             double2 *__restrict__ part) {
   double sr = 0, si = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-    double2 v = buf[i], c = carrier_at((unsigned long long)i, u_hi, u_lo, logrho);
-    double nx = v.x * c.x - v.y * c.y, ny = v.x * c.y + v.y * c.x;
-    buf[i] = make_double2(nx, ny);
+    const double2 v = iq_sample(iq, lo, i, flip), c = carrier_at((unsigned long long)i, u_hi, u_lo, logrho);
+    const double nx = v.x * c.x - v.y * c.y, ny = v.x * c.y + v.y * c.x;
     sr += nx; si += ny;
   }
 #pragma unroll
@@ -685,14 +795,16 @@ __global__ void k_sum2(const double2 *__restrict__ part, int n, double2 *out) {
   if (threadIdx.x == 0) *out = ws[0];
 }
 // pass 2 (pmdemod.c:341-348) + quantise (:360-368)
-__global__ __launch_bounds__(256) void k_rotate(double2 *__restrict__ buf, int N, double ur, double ui, double amp,
+__global__ __launch_bounds__(256) void k_rotate(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
+                                                unsigned long long u_hi, unsigned long long u_lo, double logrho,
+                                                double ur, double ui, double amp,
                                                 int16_t *__restrict__ out16, double *__restrict__ pre,
                                                 double2 *__restrict__ part) {
   double acc = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-    double2 v = buf[i];
+    const double2 s0 = iq_sample(iq, lo, i, flip), c = carrier_at((unsigned long long)i, u_hi, u_lo, logrho);
+    const double2 v = make_double2(s0.x * c.x - s0.y * c.y, s0.x * c.y + s0.y * c.x);       // what pass 1 summed
     double nx = v.x * ur - v.y * ui, ny = v.x * ui + v.y * ur;
-    buf[i] = make_double2(nx, ny);
     double d = nx - amp;
     acc += d * d;
     double q = ny * 0.70710678118654752440;       // M_SQRT1_2
@@ -707,6 +819,30 @@ __global__ __launch_bounds__(256) void k_rotate(double2 *__restrict__ buf, int N
   if (threadIdx.x == 0) part[blockIdx.x] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], 0.0);
 }
 
+template <int LG, bool FROM_IQ>
+static int launch_pass(Pmd *h, const double2 *src, double2 *dst, int s) {
+  constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FT * (R1 > R2 ? R1 : R2);
+  const size_t lds = sizeof(double2) * R * FT;
+  static bool attr_set = false;                      // 64 KiB of dynamic LDS at R = 256
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, FROM_IQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    attr_set = true;
+  }
+  k_fft_pass<LG, FROM_IQ><<<h->N / R / FT, TH, lds, h->st>>>(src, (const short2 *)h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip,
+                                                        dst, h->twA, h->twB, h->twR, h->N, s);
+  return 0;
+}
+template <bool FROM_IQ>
+static int launch_pass_lg(Pmd *h, int lg, const double2 *src, double2 *dst, int s) {
+  switch (lg) {
+  case 5: return launch_pass<5, FROM_IQ>(h, src, dst, s);
+  case 6: return launch_pass<6, FROM_IQ>(h, src, dst, s);
+  case 7: return launch_pass<7, FROM_IQ>(h, src, dst, s);
+  case 8: return launch_pass<8, FROM_IQ>(h, src, dst, s);
+  }
+  return -1;
+}
+
 extern "C" void *pmd_create(int fftsize) {
   Pmd *h = nullptr;
   int lg = 0;
@@ -718,16 +854,24 @@ extern "C" void *pmd_create(int fftsize) {
   h->N = fftsize; h->logN = lg;
   CHK(hipSetDevice(h->dev));
   CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
-  CHK(hipMalloc(&h->buf, sizeof(double2) * (size_t)fftsize));
   CHK(hipMalloc(&h->spec, sizeof(double2) * (size_t)fftsize));
   CHK(hipMalloc(&h->tmp, sizeof(double2) * (size_t)fftsize));
-  CHK(hipMalloc(&h->tw, sizeof(double2) * (size_t)(fftsize / 2)));
   CHK(hipMalloc(&h->d_iq, sizeof(int16_t) * 2 * (size_t)fftsize));
   CHK(hipMalloc(&h->d_out16, sizeof(int16_t) * (size_t)fftsize));
   CHK(hipMalloc(&h->d_pre, sizeof(double) * (size_t)fftsize));
   h->red_cap = sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak) + sizeof(PeakRec) * RED_BLOCKS;
   CHK(hipMalloc(&h->d_red, h->red_cap));
-  k_twiddles<<<(fftsize / 2 + 255) / 256, 256, 0, h->st>>>(h->tw, fftsize);
+  if (lg >= 12 && !getenv("ISEE3DSP_FFT_REGISTER_RADIX")) {
+    const int nA = fftsize / 4096 > 0 ? fftsize / 4096 : 1;
+    CHK(hipMalloc(&h->twA, sizeof(double2) * (size_t)nA));
+    CHK(hipMalloc(&h->twB, sizeof(double2) * 4096));
+    CHK(hipMalloc(&h->twR, sizeof(double2) * 256));
+    k_twiddles2<<<(nA > 4096 ? nA : 4096) / 256, 256, 0, h->st>>>(h->twA, h->twB, h->twR, fftsize);
+  } else {                                           // small transforms: register-radix stages on a double copy of the block
+    CHK(hipMalloc(&h->buf, sizeof(double2) * (size_t)fftsize));
+    CHK(hipMalloc(&h->tw, sizeof(double2) * (size_t)(fftsize / 2)));
+    k_twiddles<<<(fftsize / 2 + 255) / 256, 256, 0, h->st>>>(h->tw, fftsize);
+  }
   CHK(hipGetLastError());
   CHK(hipStreamSynchronize(h->st));
   return h;
@@ -741,6 +885,7 @@ extern "C" void pmd_destroy(void *p) {
   (void)hipSetDevice(h->dev);
   if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
+  (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red);
   free(h);
 }
@@ -758,17 +903,20 @@ extern "C" int pmd_set_dechirp(void *p, const double *lophase_ri) {
 fail:
   return -1;
 }
+// The block is only announced here (a host block is copied to the handle's staging buffer): the FFT's first pass, the
+// spin-down sum and the output kernel each read the int16 pairs themselves.  A DEVICE block must therefore stay valid
+// and unchanged until pmd_mix_quantise has returned.
 extern "C" int pmd_load(void *p, const int16_t *iq, int is_dev, int flip) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;
   CHK(hipSetDevice(h->dev));
-  {
-    const int16_t *src = iq;
-    if (!is_dev) {
-      CHK(hipMemcpyAsync(h->d_iq, iq, sizeof(int16_t) * 2 * (size_t)h->N, hipMemcpyHostToDevice, h->st));
-      src = h->d_iq;
-    }
-    k_pmd_load<<<(h->N + 255) / 256, 256, 0, h->st>>>((const short2 *)src, h->buf, h->have_lo ? h->lo : nullptr, h->N, flip);
+  if (!is_dev) {
+    CHK(hipMemcpyAsync(h->d_iq, iq, sizeof(int16_t) * 2 * (size_t)h->N, hipMemcpyHostToDevice, h->st));
+    h->cur_iq = h->d_iq;
+  } else h->cur_iq = iq;
+  h->cur_flip = flip;
+  if (h->buf) {
+    k_pmd_load<<<(h->N + 255) / 256, 256, 0, h->st>>>((const short2 *)h->cur_iq, h->buf, h->have_lo ? h->lo : nullptr, h->N, flip);
     CHK(hipGetLastError());
   }
   return 0;
@@ -779,27 +927,45 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;
   if (firstbin < 0 || lastbin > h->N || firstbin > lastbin) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: bad bin range"); return -1; }
+  if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: no block loaded"); return -1; }
   CHK(hipSetDevice(h->dev));
   {
-    // stages ping-pong so that the last one lands in spec; buf is never written.  Radix plan: the
-    // small remainder radix first (its short output runs matter least while s is tiny), then radix 16.
-    int radices[12], nst = 0, rem = h->logN;
-    if (getenv("ISEE3DSP_FFT_RADIX2")) { while (rem > 0) { radices[nst++] = 2; rem--; } }
-    else {
-      if (rem % 4) { radices[nst++] = 1 << (rem % 4); rem -= rem % 4; }
-      while (rem > 0) { radices[nst++] = 16; rem -= 4; }
-    }
-    const double2 *src = h->buf;
-    int s = 1;
-    for (int st = 0; st < nst; st++) {
-      bool to_spec = ((nst - 1 - st) & 1) == 0;
-      double2 *dst = to_spec ? h->spec : h->tmp;
-      const int R = radices[st], nthr = h->N / R;
-      if (R == 2) k_fft_stage<<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
-      else if (R == 4) k_fft_radix<4><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
-      else if (R == 8) k_fft_radix<8><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
-      else k_fft_radix<16><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
-      src = dst; s *= R;
+    if (!h->buf) {
+      // LDS-staged passes: ceil(log2 N / 8) launches of 5..8 levels each, the first one straight from the int16 block;
+      // ping-pong so that the last one lands in spec
+      const int npass = (h->logN + 7) / 8, base = h->logN / npass, extra = h->logN % npass;
+      const double2 *src = nullptr;
+      int s = 1;
+      for (int i = 0; i < npass; i++) {
+        const int lg = base + (i < extra ? 1 : 0);
+        double2 *dst = ((npass - 1 - i) & 1) == 0 ? h->spec : h->tmp;
+        if ((i == 0 ? launch_pass_lg<true>(h, lg, nullptr, dst, s) : launch_pass_lg<false>(h, lg, src, dst, s)) != 0) {
+          snprintf(g_err, sizeof g_err, "pmd_fft_peak: no pass of 2^%d points", lg);
+          return -1;
+        }
+        src = dst; s <<= lg;
+      }
+    } else {
+      // stages ping-pong so that the last one lands in spec; buf is never written.  Radix plan: the
+      // small remainder radix first (its short output runs matter least while s is tiny), then radix 16.
+      int radices[12], nst = 0, rem = h->logN;
+      if (getenv("ISEE3DSP_FFT_RADIX2")) { while (rem > 0) { radices[nst++] = 2; rem--; } }
+      else {
+        if (rem % 4) { radices[nst++] = 1 << (rem % 4); rem -= rem % 4; }
+        while (rem > 0) { radices[nst++] = 16; rem -= 4; }
+      }
+      const double2 *src = h->buf;
+      int s = 1;
+      for (int st = 0; st < nst; st++) {
+        bool to_spec = ((nst - 1 - st) & 1) == 0;
+        double2 *dst = to_spec ? h->spec : h->tmp;
+        const int R = radices[st], nthr = h->N / R;
+        if (R == 2) k_fft_stage<<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+        else if (R == 4) k_fft_radix<4><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+        else if (R == 8) k_fft_radix<8><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+        else k_fft_radix<16><<<(nthr + 255) / 256, 256, 0, h->st>>>(src, dst, h->tw, h->N, s);
+        src = dst; s *= R;
+      }
     }
     PeakRec *part = (PeakRec *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak));
     pmd_peak *dres = (pmd_peak *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64));
@@ -818,13 +984,16 @@ fail:
 extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *out16, double *pre, int out_is_dev) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;
+  if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_mix_quantise: no block loaded"); return -1; }
   CHK(hipSetDevice(h->dev));
   {
     uint64_t u_hi, u_lo; double logrho;
     pmd_carrier_params(cstep, &u_hi, &u_lo, &logrho);
     double2 *part = (double2 *)h->d_red, *tot = part + RED_BLOCKS;
+    const short2 *iq = (const short2 *)h->cur_iq;
+    const double2 *lo = h->have_lo ? h->lo : nullptr;
     int nb = (h->N + 255) / 256; if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-    k_mix<<<nb, 256, 0, h->st>>>(h->buf, h->N, u_hi, u_lo, logrho, part);
+    k_mix<<<nb, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, part);
     k_sum2<<<1, 256, 0, h->st>>>(part, nb, tot);
     double2 dc;
     CHK(hipMemcpyAsync(&dc, tot, sizeof dc, hipMemcpyDeviceToHost, h->st));
@@ -834,7 +1003,7 @@ extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *ou
     double ur = dcr / amp, ui = -dci / amp;       // conj(dc) / amp, :338
     int16_t *o16 = (out16 && out_is_dev) ? out16 : h->d_out16;
     double *opre = pre ? (out_is_dev ? pre : h->d_pre) : nullptr;
-    k_rotate<<<nb, 256, 0, h->st>>>(h->buf, h->N, ur, ui, amp, o16, opre, part);
+    k_rotate<<<nb, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, ur, ui, amp, o16, opre, part);
     k_sum2<<<1, 256, 0, h->st>>>(part, nb, tot);
     CHK(hipMemcpyAsync(&dc, tot, sizeof dc, hipMemcpyDeviceToHost, h->st));
     if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));

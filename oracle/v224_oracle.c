@@ -49,7 +49,7 @@ void *orc_v224_create(int len, int mode) {
   orc_v224 *v = calloc(1, sizeof *v);
   if (!v) return NULL;
   v->mode = mode; v->len = len;
-  v->rows = malloc((size_t)len * ORC_ROWBYTES);
+  v->rows = calloc((size_t)len, ORC_ROWBYTES);   /* the reference mallocs (port.c:58): rows never written are undefined there, zero here and in the product */
   int ok = v->rows != NULL;
   for (int b = 0; b < 2 && ok; b++) {
     if (mode == ORC_V224_LITERAL) ok = (v->m32[b] = malloc(sizeof(uint32_t) * NST)) != NULL;
