@@ -680,16 +680,27 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     dft_regs<R2>(u);
     const int q = t & (s - 1), ps = t - q;
     double2 *__restrict__ out = y + q + (size_t)R * ps;
+    // stage twiddle W_N^(ps k), k = k1 + R1 k2 (ps k < N), from the two-level table W_N^(4096 h) * W_N^l.  In the first
+    // stage ps = t differs from lane to lane and every lookup is a 64-address gather: there the thread looks up only
+    // W^(ps k1) and the step W^(ps R1) and walks k2 by multiplication (<= 15 products: ~1e-15 relative); later stages
+    // have ONE ps per tile, their lookups are broadcasts and stay direct.
+    auto tw2 = [&](unsigned idx) {
+      double2 w = twB[idx & 4095u];
+      if (idx >> 12) w = cmul(twA[idx >> 12], w);
+      return w;
+    };
+    const bool walk = FROM_IQ;                              // FROM_IQ <=> first stage <=> s == 1
+    double2 wk = make_double2(1.0, 0.0), wstep = wk;
+    if (walk && ps != 0) { wk = tw2((unsigned)ps * (unsigned)r); wstep = tw2((unsigned)ps * (unsigned)R1); }
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) {
       const int k = r + R1 * k2;
       double2 val = u[brev(k2, lg2c(R2))];
-      if (ps != 0 && k != 0) {                            // stage twiddle W_N^(ps k), ps k < N
-        const unsigned idx = (unsigned)ps * (unsigned)k;
-        double2 w = twB[idx & 4095u];
-        if (idx >> 12) w = cmul(twA[idx >> 12], w);
-        val = cmul(val, w);
+      if (ps != 0 && k != 0) {
+        if (walk) val = cmul(val, wk);
+        else val = cmul(val, tw2((unsigned)ps * (unsigned)k));
       }
+      if (walk) wk = cmul(wk, wstep);
       out[(size_t)k * s] = val;
     }
   }
