@@ -21,7 +21,9 @@ static void *hip_create(void) {
   hipctx *h = calloc(1, sizeof *h);
   if (!h) return NULL;
   h->buf = malloc((size_t)16 * DECODE_FRAMESYMBOLS);
-  for (int i = 0; i < 2; i++) h->dec[i] = create_viterbi224(DECODE_FRAMEBITS);      /* decode.c:139 */
+  /* decode.c:139 creates 1 024 rows; two frames padded to whole 15-step passes let v224hip_decode_frames run a frame's
+     traceback under the next frame's passes (the reference's call pattern through init / update / chainback is unchanged) */
+  for (int i = 0; i < 2; i++) h->dec[i] = create_viterbi224(2 * ((DECODE_FRAMEBITS + 14) / 15 * 15));
   if (!h->buf || !h->dec[0] || !h->dec[1]) { hip_destroy(h); return NULL; }
   return h;
 }

@@ -282,7 +282,7 @@ __global__ void k_chainback(const uint32_t *__restrict__ rows, const uint32_t *_
 __global__ __launch_bounds__(64) void k_chainback_spec(const uint32_t *__restrict__ rows,
                                                        const uint32_t *__restrict__ rowmeta, int len,
                                                        unsigned nbits, unsigned endstate,
-                                                       uint8_t *__restrict__ data) {
+                                                       uint8_t *__restrict__ data, unsigned row0 = 0) {
   const unsigned lane = threadIdx.x;
   const unsigned lvl = 31u - (unsigned)__clz((int)(lane + 1u));      // lane 0 -> 0, 1-2 -> 1, 3-6 -> 2, ...
   const unsigned cand = lane + 1u - (1u << lvl);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_chainback_spec(const uint32_t *__restric
     unsigned d = 0;
     if (lane < 63u && (int)lvl < steps) {
       const unsigned cs = ((cand << (V224_SBITS - lvl)) | (st >> lvl)) & V224_SMASK;
-      d = get_decision(rows, rowmeta, (int)((unsigned long long)(n - lvl) % (unsigned)len), cs);
+      d = get_decision(rows, rowmeta, (int)((unsigned long long)(row0 + n - lvl) % (unsigned)len), cs);
     }
     unsigned c = 0;
     for (int j = 0; j < steps; j++) {
@@ -560,11 +560,9 @@ extern "C" void delete_viterbi224(void *p) {
   delete v;
 }
 
-extern "C" int init_viterbi224(void *p, int starting_state) {
-  V224 *v = (V224 *)p;
-  if (!v) return -1;
+static int init_enqueue(V224 *v, int starting_state, bool wait_tracebacks) {
   HIPCHK(hipSetDevice(v->dev));
-  HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
+  if (wait_tracebacks) HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
   v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0; v->min_valid = true;
   v->layout = 0; v->fresh = true; v->start = (unsigned)starting_state & V224_SMASK;
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
@@ -573,6 +571,11 @@ extern "C" int init_viterbi224(void *p, int starting_state) {
   return 0;
 fail:
   return -1;
+}
+extern "C" int init_viterbi224(void *p, int starting_state) {
+  V224 *v = (V224 *)p;
+  if (!v) return -1;
+  return init_enqueue(v, starting_state, true);
 }
 
 // ---- profiling helpers -------------------------------------------------------------------
@@ -846,31 +849,61 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
       }
     }
     HIPCHK(hipSetDevice(v0->dev));
+    // Two things make a batch cheaper when the rings are long enough (len >= 2 * padded frame):
+    //  * a frame is padded with erasures to whole 15-step passes -- steps after the frame's last one cannot change the
+    //    decisions before it, and the traceback starts at the frame's own last row -- so no remainder pass and no
+    //    switch of the metric order;
+    //  * frames of one decoder alternate between the two halves of its ring, and a frame's traceback runs on the
+    //    decoder's second stream under the next frame's passes.
+    bool dual = true;
+    const int padbits = v0->engine == V224HIP_ENGINE_LDS15 ? (framebits + 14) / 15 * 15 : framebits;
+    for (int i = 0; i < ndec; i++) {
+      V224 *v = (V224 *)decoders[i];
+      if (v->len < 2 * padbits || v->engine != v0->engine) dual = false;
+    }
+    const int runbits = dual ? padbits : framebits;
+    const size_t stride = 2 * (size_t)runbits;
     // staging lives in decoder 0 (grow-only, kept between calls): no hipMalloc / hipFree per batch
-    for (int i = 0; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
-    if (ensure_cap(&v0->dsyms, &v0->dsyms_cap, symbytes * nframes) != 0 || ensure_cap(&v0->dout, &v0->dout_cap, outbytes * nframes) != 0) {
+    for (int i = 0; i < ndec; i++) { HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st)); HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st2)); }
+    if (ensure_cap(&v0->dsyms, &v0->dsyms_cap, stride * nframes) != 0 || ensure_cap(&v0->dout, &v0->dout_cap, outbytes * nframes) != 0) {
       snprintf(g_err, sizeof g_err, "decode_frames: device staging allocation failed");
       return -1;
     }
     v0->dsyms_off = v0->dsyms_cap;
     d_syms = v0->dsyms; d_out = v0->dout;
-    HIPCHK(hipMemcpyAsync(d_syms, syms, symbytes * nframes, hipMemcpyHostToDevice, v0->st));
+    if (stride != symbytes) HIPCHK(hipMemsetAsync(d_syms, 128, stride * nframes, v0->st));       // erasures behind every frame
+    HIPCHK(hipMemcpy2DAsync(d_syms, stride, syms, symbytes, symbytes, (size_t)nframes, hipMemcpyHostToDevice, v0->st));
     HIPCHK(hipEventRecord(v0->ev_acs[0], v0->st));
     for (int i = 1; i < ndec; i++) HIPCHK(hipStreamWaitEvent(((V224 *)decoders[i])->st, v0->ev_acs[0], 0));
     for (int f = 0; f < nframes; f++) {
       V224 *v = (V224 *)decoders[f % ndec];
-      if (init_viterbi224(v, startstate) != 0) goto fail;
-      if (enqueue_acs(v, d_syms + symbytes * f, framebits) != 0) goto fail;
-      k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f);
+      const int h = dual ? (f / ndec) & 1 : 0;
+      if (dual && f / ndec >= 2) HIPCHK(hipStreamWaitEvent(v->st, v->ev_tb[h], 0));   // this half's previous traceback is done
+      if (init_enqueue(v, startstate, !dual) != 0) goto fail;
+      v->dp = h * padbits;
+      if (enqueue_acs(v, d_syms + stride * f, runbits) != 0) goto fail;
+      if (dual) {
+        HIPCHK(hipEventRecord(v->ev_acs[h], v->st));
+        HIPCHK(hipStreamWaitEvent(v->st2, v->ev_acs[h], 0));
+        k_chainback_spec<<<1, 64, 0, v->st2>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f,
+                                              (unsigned)(h * padbits));
+        HIPCHK(hipEventRecord(v->ev_tb[h], v->st2));
+      } else
+        k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f);
     }
     HIPCHK(hipGetLastError());
-    for (int i = 1; i < ndec; i++) HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st));
+    for (int i = 0; i < ndec; i++) {
+      V224 *v = (V224 *)decoders[i];
+      if (i > 0) HIPCHK(hipStreamSynchronize(v->st));
+      HIPCHK(hipStreamSynchronize(v->st2));
+      v->dp = 0;                          // the object is left as after a plain init + update: callers re-init anyway
+    }
     HIPCHK(hipMemcpyAsync(out, d_out, outbytes * nframes, hipMemcpyDeviceToHost, v0->st));
     HIPCHK(hipStreamSynchronize(v0->st));
   }
   return 0;
 fail:
-  for (int i = 0; i < ndec; i++) if (decoders[i]) (void)hipStreamSynchronize(((V224 *)decoders[i])->st);
+  for (int i = 0; i < ndec; i++) if (decoders[i]) { (void)hipStreamSynchronize(((V224 *)decoders[i])->st); (void)hipStreamSynchronize(((V224 *)decoders[i])->st2); }
   return -1;
 }
 

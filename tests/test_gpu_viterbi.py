@@ -303,6 +303,26 @@ def test_decode_frames_batch_on_two_decoders(pkg):
         pkg.decode_frames(decs, syms, nframes - 1, framebits + 1)  # ring shorter than a frame
     for d in decs:
         d.close()
+    # rings of two padded frames: frames alternate between the ring halves, every traceback runs under the next frame's
+    # passes, the frame is padded with erasures to whole 15-step passes -- same bytes (1000 and 1024-bit frames, 1..3 decoders)
+    for fb, nd in ((1000, 2), (1024, 2), (1024, 3), (1024, 1), (333, 2)):
+        nfr = 9
+        fr = [orc.gen_coded_frame(7400 + f, fb if fb % 8 == 0 else fb + (8 - fb % 8), 2.0, 24.0)[0][:2 * fb] if f % 4 else
+              orc.gen_uniform(7500 + f, 2 * fb) for f in range(nfr)]
+        oo = orc.OracleV224(fb, orc.FAST)
+        want = []
+        for f in range(nfr):
+            oo.init(0x819fbe)
+            oo.update(fr[f], fb)
+            want.append(oo.chainback(fb, 0x155555))
+        oo.close()
+        big = [pkg.Viterbi224(2 * ((fb + 14) // 15 * 15)) for _ in range(nd)]
+        got = pkg.decode_frames(big, np.concatenate(fr), nfr, fb, 0x819fbe, 0x155555)
+        assert np.array_equal(got, np.stack(want)), (fb, nd)
+        again = pkg.decode_frames(big, np.concatenate(fr), nfr, fb, 0x819fbe, 0x155555)
+        assert np.array_equal(again, got)
+        for d in big:
+            d.close()
     o.close()
 
 
