@@ -101,6 +101,23 @@ int pmd_mix_quantise(void *h, double cstep_rad, pmd_mix *res, int16_t *out16, do
 /* test hook: copy the spectrum (fftsize complex doubles) to host */
 int pmd_get_spectrum(void *h, double *out_ri);
 
+/* ------------------------------------------------------------------ icesync.c correlator ---- */
+/* The FFT sync-vector correlator of the legacy one-shot program (icesync.c:55-208): the cross-correlation
+ * of one frame of baseband with the Manchester-coded tail + sync symbols, through transforms of corr_size points
+ * (icesync.c:102-103 hard-codes 2^20).  The vector itself (encoder + Manchester coding, :55-97) is built by the host:
+ * isee3-decoder_amd/cli/icesync_core.c. */
+#define ISYNC_FAIL (-1234567890)                   /* icesync.c:31 SYNC_FAIL */
+void *isync_create(int corr_size);                 /* power of two, 2^12 .. 2^24 */
+void  isync_destroy(void *h);
+/* icesync.c:122-135: zero-pad vec[0..synclen) to corr_size, transform, conjugate */
+int   isync_set_vector(void *h, const double *vec, int synclen);
+/* icesync.c:139-208: nsamples int16 baseband samples (host, or device with is_dev) zero-padded to corr_size, transformed,
+ * multiplied with the vector's transform, transformed back; *peakindex = index of the first maximum > 0 of the result in
+ * [low, min(high, corr_size)), folded to corr_size - index above corr_size / 2 -- or ISYNC_FAIL when every sample is zero or
+ * nothing in the window is positive.  *maxpeak (optional) = the value there; result (optional, host, corr_size doubles). */
+int   isync_search(void *h, const int16_t *samples, int nsamples, int is_dev, int low, int high,
+                   int *peakindex, double *maxpeak, double *result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,6 +252,7 @@ DSP_SYMBOLS = [
     "symd_store_reset", "symd_store_slide", "symd_store_put", "symd_store_scan",
     "pmd_create", "pmd_destroy", "pmd_set_dechirp", "pmd_load", "pmd_fft_peak", "pmd_mix_quantise",
     "pmd_get_spectrum",
+    "isync_create", "isync_destroy", "isync_set_vector", "isync_search",
 ]
 
 
@@ -334,6 +335,13 @@ def dsp_lib():
     L.pmd_fft_peak.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(PmdPeak)]
     L.pmd_mix_quantise.argtypes = [C.c_void_p, C.c_double, C.POINTER(PmdMix), C.c_void_p, C.c_void_p, C.c_int]
     L.pmd_get_spectrum.argtypes = [C.c_void_p, C.c_void_p]
+    L.isync_create.restype = C.c_void_p
+    L.isync_create.argtypes = [C.c_int]
+    L.isync_destroy.argtypes = [C.c_void_p]
+    L.isync_destroy.restype = None
+    L.isync_set_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.isync_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                               C.POINTER(C.c_double), C.c_void_p]
     _dsp = L
     return L
 
@@ -497,6 +505,15 @@ def chain_lib():
     L.isee3_chain_last_stage_ms.restype = None
     L.isee3_chain_run_fd.argtypes = [C.POINTER(ChainOpts), C.c_int, C.c_int]
     L.isee3_chain_last_error.restype = C.c_char_p
+    L.icesync_sync_vector.argtypes = [C.c_double, C.c_void_p, C.c_int]
+    L.icesync_corr_create.restype = C.c_void_p
+    L.icesync_corr_create.argtypes = [C.c_double, C.c_double, C.c_int]
+    L.icesync_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.icesync_corr_framesamples.restype = C.c_double
+    L.icesync_corr_framesamples.argtypes = [C.c_void_p]
+    L.icesync_corr_synclen.argtypes = [C.c_void_p]
+    L.icesync_corr_destroy.argtypes = [C.c_void_p]
+    L.icesync_corr_destroy.restype = None
     _chain = L
     return L
 
@@ -536,6 +553,50 @@ def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=2
         L.isee3_chain_last_stage_ms(C.byref(ms))
         stage_ms[:] = [ms[0], ms[1], ms[2]]
     return out.raw[:n.value]
+
+
+ICESYNC_SYMBOLS = ["icesync_sync_vector", "icesync_corr_create", "icesync_corr_search", "icesync_corr_framesamples",
+                   "icesync_corr_synclen", "icesync_corr_destroy"]
+ICESYNC_FAIL = -1234567890
+
+
+def icesync_sync_vector(symbolsamples):
+    """icesync.c:55-97: the Manchester-coded last 34 symbols of the encoded tail + sync word (host code, no GPU)."""
+    cap = int(34 * symbolsamples + 2)
+    v = np.zeros(cap, np.float64)
+    n = chain_lib().icesync_sync_vector(float(symbolsamples), v.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("icesync_sync_vector failed")
+    return v[:n]
+
+
+class IcesyncCorrelator:
+    """generate_sync + fft_sync_search of the reference's icesync.c (:55-208) on the GPU FFT (isync_* in libisee3dsp_hip.so)."""
+
+    def __init__(self, samprate=250000.0, symrate=1024.475, corr_size_log2=0):
+        self.L = chain_lib()
+        self.h = self.L.icesync_corr_create(float(samprate), float(symrate), int(corr_size_log2))
+        if not self.h:
+            raise RuntimeError("icesync_corr_create failed: " + dsp_error())
+        self.framesamples = self.L.icesync_corr_framesamples(self.h)
+        self.synclen = self.L.icesync_corr_synclen(self.h)
+
+    def search(self, samples, low, high):
+        s = np.ascontiguousarray(samples, dtype=np.int16)
+        assert len(s) >= self.framesamples
+        mp = C.c_double(0)
+        return self.L.icesync_corr_search(self.h, s.ctypes.data, int(low), int(high), C.byref(mp)), mp.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.icesync_corr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def release_chain_objects():

@@ -648,7 +648,13 @@ template <> struct PassShape<7> { static constexpr int R1 = 16, R2 = 8; };
 template <> struct PassShape<8> { static constexpr int R1 = 16, R2 = 16; };
 constexpr int lg2c(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 
-template <int LG, bool FROM_IQ>
+// SRC: where the first stage's input comes from -- 0 a double2 array, 1 int16 (I, Q) pairs (pmdemod), 2 int16 REAL samples
+// zero-padded beyond nvalid (icesync.c:151-163), 3 conj(x[i] * v[i]) (the inverse transform of a product: icesync.c:166-170)
+#define SRC_C2 0
+#define SRC_IQ 1
+#define SRC_REAL16 2
+#define SRC_CONJPROD 3
+template <int LG, int SRC, bool FIRST>
 __global__ __launch_bounds__(FT * (PassShape<LG>::R1 > PassShape<LG>::R2 ? PassShape<LG>::R1 : PassShape<LG>::R2))
 void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip,
                 double2 *__restrict__ y, const double2 *__restrict__ twA, const double2 *__restrict__ twB,
@@ -662,7 +668,10 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
 #pragma unroll
     for (int b = 0; b < R1; b++) {
       const int i = t + (r + R2 * b) * stride;
-      if constexpr (FROM_IQ) v[b] = iq_sample(iq, lo, i, flip); else v[b] = x[i];
+      if constexpr (SRC == SRC_IQ) v[b] = iq_sample(iq, lo, i, flip);
+      else if constexpr (SRC == SRC_REAL16) v[b] = make_double2(i < flip ? (double)reinterpret_cast<const int16_t *>(iq)[i] : 0.0, 0.0);   // flip = nvalid
+      else if constexpr (SRC == SRC_CONJPROD) { const double2 p = cmul(x[i], lo[i]); v[b] = make_double2(p.x, -p.y); }
+      else v[b] = x[i];
     }
     dft_regs<R1>(v);
 #pragma unroll
@@ -689,7 +698,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
       if (idx >> 12) w = cmul(twA[idx >> 12], w);
       return w;
     };
-    const bool walk = FROM_IQ;                              // FROM_IQ <=> first stage <=> s == 1
+    const bool walk = FIRST;                                // first stage <=> s == 1
     double2 wk = make_double2(1.0, 0.0), wstep = wk;
     if (walk && ps != 0) { wk = tw2((unsigned)ps * (unsigned)r); wstep = tw2((unsigned)ps * (unsigned)R1); }
 #pragma unroll
@@ -830,28 +839,55 @@ __global__ __launch_bounds__(256) void k_rotate(const short2 *__restrict__ iq, c
   if (threadIdx.x == 0) part[blockIdx.x] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], 0.0);
 }
 
-template <int LG, bool FROM_IQ>
-static int launch_pass(Pmd *h, const double2 *src, double2 *dst, int s) {
+// what a transform needs besides its data: the twiddle tables of its size and a stream
+struct FftCtx { int N, logN; const double2 *twA, *twB, *twR; hipStream_t st; };
+struct FftSrc { const double2 *x; const void *i16; const double2 *aux; int iparam; };   // see SRC_*: (x) | (iq, lo, flip) | (samples, -, nvalid) | (x, v)
+
+template <int LG, int SRC, bool FIRST>
+static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FT * (R1 > R2 ? R1 : R2);
   const size_t lds = sizeof(double2) * R * FT;
   static bool attr_set = false;                      // 64 KiB of dynamic LDS at R = 256
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, FROM_IQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set = true;
   }
-  k_fft_pass<LG, FROM_IQ><<<h->N / R / FT, TH, lds, h->st>>>(src, (const short2 *)h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip,
-                                                        dst, h->twA, h->twB, h->twR, h->N, s);
+  k_fft_pass<LG, SRC, FIRST><<<c.N / R / FT, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
   return 0;
 }
-template <bool FROM_IQ>
-static int launch_pass_lg(Pmd *h, int lg, const double2 *src, double2 *dst, int s) {
+template <int SRC, bool FIRST>
+static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, double2 *dst, int s) {
   switch (lg) {
-  case 5: return launch_pass<5, FROM_IQ>(h, src, dst, s);
-  case 6: return launch_pass<6, FROM_IQ>(h, src, dst, s);
-  case 7: return launch_pass<7, FROM_IQ>(h, src, dst, s);
-  case 8: return launch_pass<8, FROM_IQ>(h, src, dst, s);
+  case 5: return launch_pass<5, SRC, FIRST>(c, in, dst, s);
+  case 6: return launch_pass<6, SRC, FIRST>(c, in, dst, s);
+  case 7: return launch_pass<7, SRC, FIRST>(c, in, dst, s);
+  case 8: return launch_pass<8, SRC, FIRST>(c, in, dst, s);
   }
   return -1;
+}
+// forward unnormalised transform of N = 2^logN >= 2^12 points: ceil(logN / 8) LDS-staged passes of 5..8 levels each, the
+// first one reading `in` in the form SRC; ping-pong between out and tmp so that the last pass lands in `out`
+template <int SRC>
+static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 *tmp) {
+  const int npass = (c.logN + 7) / 8, base = c.logN / npass, extra = c.logN % npass;
+  FftSrc cur = in;
+  int s = 1;
+  for (int i = 0; i < npass; i++) {
+    const int lg = base + (i < extra ? 1 : 0);
+    double2 *dst = ((npass - 1 - i) & 1) == 0 ? out : tmp;
+    if ((i == 0 ? launch_pass_lg<SRC, true>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false>(c, lg, cur, dst, s)) != 0) return -1;
+    cur = FftSrc{dst, nullptr, nullptr, 0}; s <<= lg;
+  }
+  return 0;
+}
+static int fft_tables(FftCtx *c, int N, double2 **twA, double2 **twB, double2 **twR, hipStream_t st) {
+  int lg = 0; while ((1 << lg) < N) lg++;
+  const int nA = N / 4096 > 0 ? N / 4096 : 1;
+  if (hipMalloc(twA, sizeof(double2) * (size_t)nA) != hipSuccess || hipMalloc(twB, sizeof(double2) * 4096) != hipSuccess ||
+      hipMalloc(twR, sizeof(double2) * 256) != hipSuccess) return -1;
+  k_twiddles2<<<(nA > 4096 ? nA : 4096) / 256, 256, 0, st>>>(*twA, *twB, *twR, N);
+  *c = FftCtx{N, lg, *twA, *twB, *twR, st};
+  return 0;
 }
 
 extern "C" void *pmd_create(int fftsize) {
@@ -873,11 +909,8 @@ extern "C" void *pmd_create(int fftsize) {
   h->red_cap = sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak) + sizeof(PeakRec) * RED_BLOCKS;
   CHK(hipMalloc(&h->d_red, h->red_cap));
   if (lg >= 12 && !getenv("ISEE3DSP_FFT_REGISTER_RADIX")) {
-    const int nA = fftsize / 4096 > 0 ? fftsize / 4096 : 1;
-    CHK(hipMalloc(&h->twA, sizeof(double2) * (size_t)nA));
-    CHK(hipMalloc(&h->twB, sizeof(double2) * 4096));
-    CHK(hipMalloc(&h->twR, sizeof(double2) * 256));
-    k_twiddles2<<<(nA > 4096 ? nA : 4096) / 256, 256, 0, h->st>>>(h->twA, h->twB, h->twR, fftsize);
+    FftCtx c;
+    if (fft_tables(&c, fftsize, &h->twA, &h->twB, &h->twR, h->st) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: twiddle tables"); goto fail; }
   } else {                                           // small transforms: register-radix stages on a double copy of the block
     CHK(hipMalloc(&h->buf, sizeof(double2) * (size_t)fftsize));
     CHK(hipMalloc(&h->tw, sizeof(double2) * (size_t)(fftsize / 2)));
@@ -942,20 +975,10 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
   CHK(hipSetDevice(h->dev));
   {
     if (!h->buf) {
-      // LDS-staged passes: ceil(log2 N / 8) launches of 5..8 levels each, the first one straight from the int16 block;
-      // ping-pong so that the last one lands in spec
-      const int npass = (h->logN + 7) / 8, base = h->logN / npass, extra = h->logN % npass;
-      const double2 *src = nullptr;
-      int s = 1;
-      for (int i = 0; i < npass; i++) {
-        const int lg = base + (i < extra ? 1 : 0);
-        double2 *dst = ((npass - 1 - i) & 1) == 0 ? h->spec : h->tmp;
-        if ((i == 0 ? launch_pass_lg<true>(h, lg, nullptr, dst, s) : launch_pass_lg<false>(h, lg, src, dst, s)) != 0) {
-          snprintf(g_err, sizeof g_err, "pmd_fft_peak: no pass of 2^%d points", lg);
-          return -1;
-        }
-        src = dst; s <<= lg;
-      }
+      // LDS-staged passes, the first one straight from the int16 block
+      const FftCtx c{h->N, h->logN, h->twA, h->twB, h->twR, h->st};
+      const FftSrc in{nullptr, h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip};
+      if (fft_forward<SRC_IQ>(c, in, h->spec, h->tmp) != 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: FFT launch failed"); return -1; }
     } else {
       // stages ping-pong so that the last one lands in spec; buf is never written.  Radix plan: the
       // small remainder radix first (its short output runs matter least while s is tiny), then radix 16.
@@ -1026,6 +1049,167 @@ extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *ou
 fail:
   return -1;
 }
+// ===========================================================================================
+// icesync.c:55-208 -- FFT sync-vector correlator
+// ===========================================================================================
+// Corr_result[n] = sum_m samples[m] * vec[m - n] through three transforms of corr_size points: the vector's (once per
+// vector, conjugated: icesync.c:122-135), the zero-padded frame's (:151-163), and the inverse of their product (:166-170;
+// FFTW's unnormalised c2r = Re(FFT(conj(Y)))).  Then the first maximum > 0 in [low, high), folded above size/2 (:188-206).
+struct Isync {
+  int dev; hipStream_t st;
+  int N, logN; FftCtx c;
+  double2 *twA, *twB, *twR;
+  double2 *V, *D, *R, *tmp;        // conj(FFT(vec)), FFT(frame), result, ping-pong
+  int16_t *d_s; int have_vec;
+  void *d_red;
+};
+#define ISYNC_FAIL (-1234567890)     /* icesync.c:31 SYNC_FAIL */
+__device__ __forceinline__ bool first_better(double e, int i, double be, int bi) { return e > be || (e == be && bi >= 0 && i < bi); }
+__global__ __launch_bounds__(256) void k_conj_inplace(double2 *v, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i].y = -v[i].y;
+}
+// all samples zero?  (icesync.c:151-158) -> *flag stays 0
+__global__ __launch_bounds__(256) void k_any_nonzero(const int16_t *__restrict__ s, int n, unsigned *flag) {
+  int nz = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) nz |= s[i] != 0;
+  if (__syncthreads_or(nz) && threadIdx.x == 0) atomicOr(flag, 1u);
+}
+__global__ __launch_bounds__(256) void k_isync_peak_partial(const double2 *__restrict__ r, int first, int last, PeakRec *__restrict__ part) {
+  double be = 0.0; int bi = -1;                       // maxpeak starts at 0: only positive values count (icesync.c:189-198)
+  for (int i = first + blockIdx.x * 256 + threadIdx.x; i < last; i += gridDim.x * 256) {
+    const double e = r[i].x;
+    if (first_better(e, i, be, bi)) { be = e; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double oe = __shfl_xor(be, o, 64); int oi = __shfl_xor(bi, o, 64);
+    if (oi >= 0 && first_better(oe, oi, be, bi)) { be = oe; bi = oi; }
+  }
+  __shared__ PeakRec ws[4];
+  if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6].e = be; ws[threadIdx.x >> 6].idx = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) if (ws[w].idx >= 0 && first_better(ws[w].e, ws[w].idx, be, bi)) { be = ws[w].e; bi = ws[w].idx; }
+    part[blockIdx.x].e = be; part[blockIdx.x].idx = bi;
+  }
+}
+__global__ __launch_bounds__(256) void k_isync_peak_final(const PeakRec *__restrict__ part, int nparts, PeakRec *out) {
+  __shared__ PeakRec ws[256];
+  double be = 0.0; int bi = -1;
+  for (int p = threadIdx.x; p < nparts; p += 256) if (part[p].idx >= 0 && first_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
+  ws[threadIdx.x].e = be; ws[threadIdx.x].idx = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o && ws[threadIdx.x + o].idx >= 0 &&
+        first_better(ws[threadIdx.x + o].e, ws[threadIdx.x + o].idx, ws[threadIdx.x].e, ws[threadIdx.x].idx)) ws[threadIdx.x] = ws[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = ws[0];
+}
+
+extern "C" void *isync_create(int corr_size) {
+  Isync *h = nullptr;
+  int lg = 0;
+  while ((1 << lg) < corr_size) lg++;
+  if (corr_size < 4096 || (1 << lg) != corr_size || lg > 24) { snprintf(g_err, sizeof g_err, "isync_create: size %d not a power of two in [2^12, 2^24]", corr_size); return nullptr; }
+  h = (Isync *)calloc(1, sizeof(Isync));
+  if (!h) return nullptr;
+  h->dev = g_device >= 0 ? g_device : 0;
+  h->N = corr_size; h->logN = lg;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  if (fft_tables(&h->c, corr_size, &h->twA, &h->twB, &h->twR, h->st) != 0) { snprintf(g_err, sizeof g_err, "isync_create: twiddle tables"); goto fail; }
+  CHK(hipMalloc(&h->V, sizeof(double2) * (size_t)corr_size));
+  CHK(hipMalloc(&h->D, sizeof(double2) * (size_t)corr_size));
+  CHK(hipMalloc(&h->R, sizeof(double2) * (size_t)corr_size));
+  CHK(hipMalloc(&h->tmp, sizeof(double2) * (size_t)corr_size));
+  CHK(hipMalloc(&h->d_s, sizeof(int16_t) * (size_t)corr_size));
+  CHK(hipMalloc(&h->d_red, sizeof(PeakRec) * (RED_BLOCKS + 2) + 16));
+  CHK(hipStreamSynchronize(h->st));
+  return h;
+fail:
+  isync_destroy(h);
+  return nullptr;
+}
+extern "C" void isync_destroy(void *p) {
+  Isync *h = (Isync *)p;
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
+  (void)hipFree(h->V); (void)hipFree(h->D); (void)hipFree(h->R); (void)hipFree(h->tmp); (void)hipFree(h->d_s); (void)hipFree(h->d_red);
+  free(h);
+}
+// icesync.c:122-135: vec[0..synclen) zero-padded to the transform size, transformed, conjugated
+extern "C" int isync_set_vector(void *p, const double *vec, int synclen) {
+  Isync *h = (Isync *)p;
+  double *host = nullptr;
+  if (!h || !vec || synclen < 1 || synclen > h->N) { snprintf(g_err, sizeof g_err, "isync_set_vector: bad arguments"); return -1; }
+  CHK(hipSetDevice(h->dev));
+  host = (double *)calloc((size_t)h->N, 2 * sizeof(double));
+  if (!host) return -1;
+  for (int i = 0; i < synclen; i++) host[2 * i] = vec[i];
+  CHK(hipMemcpy(h->D, host, sizeof(double2) * (size_t)h->N, hipMemcpyHostToDevice));
+  free(host); host = nullptr;
+  if (fft_forward<SRC_C2>(h->c, FftSrc{h->D, nullptr, nullptr, 0}, h->V, h->tmp) != 0) { snprintf(g_err, sizeof g_err, "isync_set_vector: FFT launch failed"); return -1; }
+  k_conj_inplace<<<(h->N + 255) / 256, 256, 0, h->st>>>(h->V, h->N);
+  CHK(hipGetLastError());
+  CHK(hipStreamSynchronize(h->st));
+  h->have_vec = 1;
+  return 0;
+fail:
+  free(host);
+  return -1;
+}
+// icesync.c:139-208.  samples: nsamples (= (int)ceil of the reference's Framesamples loop bound) int16 values, host or
+// device memory.  *peakindex = the folded index, or ISYNC_FAIL (all samples zero, or no positive correlation in the
+// window); *maxpeak = Corr_result at the peak (0 on failure).  result_ri (optional, host): Corr_result as N doubles.
+extern "C" int isync_search(void *p, const int16_t *samples, int nsamples, int is_dev, int low, int high,
+                            int *peakindex, double *maxpeak, double *result) {
+  Isync *h = (Isync *)p;
+  if (!h || !samples || nsamples < 0 || nsamples > h->N || low < 0 || high < 0 || !peakindex) { snprintf(g_err, sizeof g_err, "isync_search: bad arguments"); return -1; }
+  if (!h->have_vec) { snprintf(g_err, sizeof g_err, "isync_search: no sync vector set"); return -1; }
+  CHK(hipSetDevice(h->dev));
+  {
+    const int16_t *src = samples;
+    if (!is_dev) { CHK(hipMemcpyAsync(h->d_s, samples, sizeof(int16_t) * (size_t)nsamples, hipMemcpyHostToDevice, h->st)); src = h->d_s; }
+    unsigned *flag = (unsigned *)((char *)h->d_red + sizeof(PeakRec) * (RED_BLOCKS + 2));
+    PeakRec *part = (PeakRec *)h->d_red, *res = part + RED_BLOCKS;
+    unsigned hflag = 0; PeakRec hres;
+    CHK(hipMemsetAsync(flag, 0, sizeof(unsigned), h->st));
+    int nb = (nsamples + 255) / 256; if (nb > RED_BLOCKS) nb = RED_BLOCKS; if (nb < 1) nb = 1;
+    k_any_nonzero<<<nb, 256, 0, h->st>>>(src, nsamples, flag);
+    if (fft_forward<SRC_REAL16>(h->c, FftSrc{nullptr, src, nullptr, nsamples}, h->D, h->tmp) != 0 ||
+        fft_forward<SRC_CONJPROD>(h->c, FftSrc{h->D, nullptr, h->V, 0}, h->R, h->tmp) != 0) {
+      snprintf(g_err, sizeof g_err, "isync_search: FFT launch failed");
+      return -1;
+    }
+    if (high > h->N) high = h->N;                     // icesync.c:192-193
+    int np = (high - low + 255) / 256; if (np > RED_BLOCKS) np = RED_BLOCKS; if (np < 1) np = 1;
+    k_isync_peak_partial<<<np, 256, 0, h->st>>>(h->R, low, high, part);
+    k_isync_peak_final<<<1, 256, 0, h->st>>>(part, np, res);
+    CHK(hipMemcpyAsync(&hflag, flag, sizeof hflag, hipMemcpyDeviceToHost, h->st));
+    CHK(hipMemcpyAsync(&hres, res, sizeof hres, hipMemcpyDeviceToHost, h->st));
+    if (result) {
+      CHK(hipStreamSynchronize(h->st));
+      double2 *tmp = (double2 *)malloc(sizeof(double2) * (size_t)h->N);
+      if (!tmp) return -1;
+      if (hipMemcpy(tmp, h->R, sizeof(double2) * (size_t)h->N, hipMemcpyDeviceToHost) != hipSuccess) { free(tmp); return -1; }
+      for (int i = 0; i < h->N; i++) result[i] = tmp[i].x;
+      free(tmp);
+    }
+    CHK(hipStreamSynchronize(h->st));
+    if (maxpeak) *maxpeak = 0;
+    if (!hflag || hres.idx < 0 || hres.e == 0) { *peakindex = ISYNC_FAIL; return 0; }     // :157-158, :200-203
+    if (maxpeak) *maxpeak = hres.e;
+    *peakindex = hres.idx > h->N / 2 ? h->N - hres.idx : hres.idx;                        // :204-205
+  }
+  return 0;
+fail:
+  return -1;
+}
+
 extern "C" int pmd_get_spectrum(void *p, double *out_ri) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;

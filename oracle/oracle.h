@@ -134,4 +134,10 @@ void   orc_fft_forward(const double *in_ri, double *out_ri, int n);
 #ifdef __cplusplus
 }
 #endif
+/* ---- icesync.c:55-208 FFT sync-vector correlator (icesync_oracle.c; PARITY UNPINNED: FFTW3 absent) ---- */
+#define ORC_SYNC_FAIL (-1234567890)                          /* icesync.c:31 */
+int orc_icesync_sync_vector(double symbolsamples, double *vec, int cap);
+int orc_icesync_search(const double *vec, int synclen, int corr_size, const int16_t *samples, double framesamples,
+                       int low, int high, double *maxpeak, double *result);
+
 #endif

@@ -91,6 +91,9 @@ def lib():
         L.orc_pmdemod.argtypes = [C.c_void_p, i16p, C.c_size_t, i16p, C.POINTER(C.c_double),
                                   C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.orc_fft_forward.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+        L.orc_icesync_sync_vector.argtypes = [C.c_double, C.c_void_p, C.c_int]
+        L.orc_icesync_search.argtypes = [C.c_void_p, C.c_int, C.c_int, i16p, C.c_double, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double), C.c_void_p]
         _lib = L
     return _lib
 
@@ -332,3 +335,25 @@ def ref_cli(name, args, stdin_bytes, timeout=3600):
     p = subprocess.run([exe] + list(args), input=stdin_bytes, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=timeout, check=True)
     return p.stdout
+
+
+ICESYNC_FAIL = -1234567890
+
+
+def icesync_sync_vector(symbolsamples):
+    cap = int(34 * symbolsamples + 2)
+    v = np.zeros(cap, np.float64)
+    n = lib().orc_icesync_sync_vector(float(symbolsamples), v.ctypes.data, cap)
+    assert n > 0
+    return v[:n]
+
+
+def icesync_search(vec, corr_size, samples, framesamples, low, high, want_result=False):
+    """oracle fft_sync_search (icesync.c:139-208): (peakindex or ICESYNC_FAIL, maxpeak[, Corr_result])"""
+    vec = np.ascontiguousarray(vec, dtype=np.float64)
+    samples = np.ascontiguousarray(samples, dtype=np.int16)
+    mp = C.c_double(0)
+    res = np.zeros(corr_size, np.float64) if want_result else None
+    pk = lib().orc_icesync_search(vec.ctypes.data, len(vec), int(corr_size), _ptr(samples, i16p), float(framesamples),
+                                  int(low), int(high), C.byref(mp), res.ctypes.data if want_result else None)
+    return (pk, mp.value, res) if want_result else (pk, mp.value)

@@ -54,7 +54,7 @@ def test_dsp_header_vs_library():
     L = C.CDLL(so)
     txt = open(os.path.join(ROOT, "include", "isee3_dsp_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = sorted(set(re.findall(r"\b((?:symd|pmd|isee3dsp)_[a-z0-9_]+)\s*\(", txt)))
+    names = sorted(set(re.findall(r"\b((?:symd|pmd|isync|isee3dsp)_[a-z0-9_]+)\s*\(", txt)))
     assert len(names) >= 14
     for n in names:
         assert hasattr(L, n), "missing export %s" % n
@@ -75,5 +75,15 @@ def test_chain_header_vs_library():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "isee3_chain.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(isee3_chain_[a-z0-9_]+)\s*\(", txt)))
     assert names == sorted(pkg.CHAIN_SYMBOLS)
+    for n in names:
+        assert hasattr(L, n)
+
+
+def test_icesync_header_vs_library():
+    pkg = load_pkg()
+    L = C.CDLL(pkg.lib_path("libisee3chain.so"))
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "isee3_icesync.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(icesync_[a-z0-9_]+)\s*\(", txt)))
+    assert names == sorted(pkg.ICESYNC_SYMBOLS) and len(names) == 6
     for n in names:
         assert hasattr(L, n)

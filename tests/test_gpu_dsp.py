@@ -450,3 +450,50 @@ def test_timesearch_beyond_2_pow_53_takes_the_ordered_path(pkg, monkeypatch):
             assert en[t] == ordered(t)
     assert en.max() >= 2.0 ** 53
     eng.close()
+
+
+def test_icesync_correlator_vs_oracle(pkg):
+    """the FFT sync-vector correlator of icesync.c:55-208 on the GPU FFT (isync_* + include/isee3_icesync.h)
+    against the oracle restatement: same peak index, peak value and whole Corr_result within 1e-9 of its maximum
+    (PARITY UNPINNED: icesync.c needs FFTW3, absent).  250 kS/s, the reference's 2^20-point transforms, a frame cut out
+    of synthetic telemetry baseband -- the peak must sit where the frame's sync symbols begin."""
+    fs, symrate = 250000.0, 1024.475
+    bb, sent = orc.gen_baseband(71, fs, 2.6, symrate=symrate, amp=1500.0, noise_sigma=3000.0)
+    co = pkg.IcesyncCorrelator(fs, symrate)
+    ss = fs / symrate
+    assert co.synclen == int(34 * ss + 1) and abs(co.framesamples - ss * 2048) < 1e-9
+    vec = orc.icesync_sync_vector(ss)
+    n = int(np.ceil(co.framesamples))
+    L = pkg.dsp_lib()
+    for begin in (0, 77777, 140000):
+        frame = bb[begin:begin + n + 8]
+        got, gmax = co.search(frame, 0, n)
+        want, wmax, wres = orc.icesync_search(vec, 1 << 20, frame, co.framesamples, 0, n, True)
+        assert got == want and got != pkg.ICESYNC_FAIL
+        assert abs(gmax - wmax) <= 1e-9 * wmax
+        # the frame's tail + sync symbols really are there: symbols (1024 - 17) * 2 .. of a frame = the vector
+        first_sync = ((2048 - 34) * ss - begin) % (2048 * ss)
+        assert min(abs(got - first_sync), abs(got - first_sync + 2048 * ss), abs(got - first_sync - 2048 * ss)) < 3
+    # whole result array through the primitive API
+    import ctypes as C
+    h = L.isync_create(1 << 20)
+    assert h and L.isync_set_vector(h, vec.ctypes.data, len(vec)) == 0
+    frame = np.ascontiguousarray(bb[5000:5000 + n])
+    res = np.zeros(1 << 20, np.float64)
+    pk, mp = C.c_int(0), C.c_double(0)
+    assert L.isync_search(h, frame.ctypes.data, n, 0, 0, n, C.byref(pk), C.byref(mp), res.ctypes.data) == 0
+    want, wmax, wres = orc.icesync_search(vec, 1 << 20, frame, float(n), 0, n, True)
+    assert pk.value == want and np.max(np.abs(res - wres)) <= 1e-9 * wmax
+    # device-resident samples, a search window, the fold rule, the two failure rules (icesync.c:157-158, 188-206)
+    d = pkg.DeviceBuffer.from_numpy(frame)
+    assert L.isync_search(h, d.ptr, n, 1, 0, n, C.byref(pk), C.byref(mp), None) == 0 and pk.value == want
+    lo = want + 5
+    assert L.isync_search(h, d.ptr, n, 1, lo, n, C.byref(pk), C.byref(mp), None) == 0
+    assert pk.value == orc.icesync_search(vec, 1 << 20, frame, float(n), lo, n)[0] != want
+    hi_lo = (1 << 20) - 3000
+    assert L.isync_search(h, d.ptr, n, 1, hi_lo, 1 << 21, C.byref(pk), C.byref(mp), None) == 0
+    assert pk.value == orc.icesync_search(vec, 1 << 20, frame, float(n), hi_lo, 1 << 21)[0]
+    z = np.zeros(n, np.int16)
+    assert L.isync_search(h, z.ctypes.data, n, 0, 0, n, C.byref(pk), C.byref(mp), None) == 0 and pk.value == pkg.ICESYNC_FAIL
+    L.isync_destroy(h)
+    co.close()
