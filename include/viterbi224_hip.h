@@ -57,6 +57,15 @@ int v224hip_stream_chunk(void *p);                 /* bits per internal chunk (o
 int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
                                 uint8_t *d_out, int warm_bits, int *nfallback);
 
+/* Streaming form of the same sharing, host buffers: the next block of a stream that decoders[*holder] is in the middle
+ * of.  A block of at least three warm-ups is shared between the holder and one other decoder (which starts fresh inside
+ * the block; seam verified as above, redone by the holder's side if it fails) and *holder moves to the decoder that
+ * stands at the end of the block; a shorter block just continues on the holder.  Feeding a stream block by block
+ * through this call gives exactly the output of v224hip_stream_decode() on one decoder.  Start with init_viterbi224 on
+ * decoders[0] and *holder = 0. */
+int v224hip_stream_decode_shared(void *const *decoders, int ndec, int *holder, const uint8_t *syms, int nbits,
+                                 int delay, uint8_t *out, int warm_bits);
+
 /* A batch of independent frames, each decoded as vtest224.c:116-118 / decode.c:220-222 do it:
  *   init_viterbi224(d, startstate); update_viterbi224_blk(d, syms + f*2*framebits, framebits);
  *   chainback_viterbi224(d, out + f*((framebits+7)/8), framebits, endstate);

@@ -30,7 +30,7 @@ V224_SYMBOLS = [
     "decodebit_viterbi224", "decodeword_viterbi224",
     "v224hip_device_count", "v224hip_set_device", "v224hip_create", "v224hip_last_error",
     "v224hip_update_dev", "v224hip_stream_decode", "v224hip_stream_decode_dev",
-    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
+    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_stream_decode_shared", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
     "v224hip_export_row", "v224hip_export_metrics", "v224hip_dev_alloc", "v224hip_dev_free",
     "v224hip_h2d", "v224hip_d2h",
 ]
@@ -78,6 +78,7 @@ def v224_lib():
     L.v224hip_stream_decode.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p]
     L.v224hip_stream_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.v224hip_stream_chunk.argtypes = [C.c_void_p]
+    L.v224hip_stream_decode_shared.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), u8p, C.c_int, C.c_int, u8p, C.c_int]
     L.v224hip_stream_decode_split.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                               C.c_int, C.POINTER(C.c_int)]
     L.v224hip_decode_frames.argtypes = [C.POINTER(C.c_void_p), C.c_int, u8p, C.c_int, C.c_int, C.c_int,
@@ -268,6 +269,22 @@ def stream_decode_split(decoders, d_syms, nbits, delay, d_out, warm_bits=14280, 
     if rc != 0:
         raise RuntimeError("v224hip_stream_decode_split: " + L.v224hip_last_error().decode())
     return nfb.value
+
+
+def stream_decode_shared(decoders, holder, syms, delay, warm_bits=4080):
+    """v224hip_stream_decode_shared: the next block (host numpy uint8 symbols) of the stream decoders[holder] is in the
+    middle of.  Returns (out uint8[nbits], new holder)."""
+    L = v224_lib()
+    syms = np.ascontiguousarray(syms, dtype=np.uint8)
+    nbits = len(syms) // 2
+    out = np.empty(nbits, dtype=np.uint8)
+    hs = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+    h = C.c_int(holder)
+    rc = L.v224hip_stream_decode_shared(hs, len(decoders), C.byref(h), syms.ctypes.data_as(u8p), nbits, int(delay),
+                                        out.ctypes.data_as(u8p), int(warm_bits))
+    if rc != 0:
+        raise RuntimeError("v224hip_stream_decode_shared: " + L.v224hip_last_error().decode())
+    return out, h.value
 
 
 def decode_frames(decoders, syms, nframes, framebits, startstate=0, endstate=0):

@@ -125,7 +125,7 @@ static void chunk_from_env(void) {
 }
 /* vdecode engine: one decoder for block-wise streaming; for one long stream (whole-input mode) a second decoder joins
  * and the stream is decoded in two halves at once, verified at the seam (v224hip_stream_decode_split) */
-typedef struct { void *d[2]; int len; } vd_ctx;
+typedef struct { void *d[2]; int len, holder; } vd_ctx;      /* holder: the decoder that carries the stream's state */
 /* Viterbi decoders (2.2 GiB decision ring, placement probe) are kept between calls too: a few, so that concurrent
  * chains each find one. */
 #define VD_POOL 4
@@ -172,11 +172,21 @@ static void *vd_create(int len) {
   v224hip_set_option(c->d[0], "chunk", g_chunk);
   return c;
 }
-static int vd_init(void *h, int s) { return init_viterbi224(((vd_ctx *)h)->d[0], s); }
-static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) {
-  TIMED(v224hip_stream_decode(((vd_ctx *)h)->d[0], s, n, d, o));
-}
+static int vd_init(void *h, int s) { vd_ctx *c = h; c->holder = 0; return init_viterbi224(c->d[0], s); }
 #define VD_SPLIT_WARM (4 * 1020)
+/* one block of the stream.  When the stages in front run ahead (they do: the Viterbi is the slowest), blocks get long, and
+ * a long block is shared between two decoders (v224hip_stream_decode_shared: the second one starts fresh inside the
+ * block, verified at the seam): same bits, two launch chains on the GPU instead of one. */
+static int vd_stream_any(vd_ctx *c, const unsigned char *s, int n, int d, unsigned char *o) {
+  if (n >= 3 * VD_SPLIT_WARM && !c->d[1] && !(getenv("ISEE3_CHAIN_SHARE") && !atoi(getenv("ISEE3_CHAIN_SHARE")))) {
+    c->d[1] = create_viterbi224(c->len);
+    if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
+  }
+  if (!c->d[1] || (getenv("ISEE3_CHAIN_SHARE") && !atoi(getenv("ISEE3_CHAIN_SHARE"))))
+    return v224hip_stream_decode(c->d[c->holder], s, n, d, o);
+  return v224hip_stream_decode_shared(c->d, 2, &c->holder, s, n, d, o, VD_SPLIT_WARM);
+}
+static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) { TIMED(vd_stream_any(h, s, n, d, o)); }
 static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigned char *o) {
   vd_ctx *c = h;
   if (n > 0x7fffffff / 2) return -1;

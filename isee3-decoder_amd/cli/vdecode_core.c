@@ -128,7 +128,7 @@ static int pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec, 
 
 int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE *out, FILE *err,
                 vdecode_result *res) {
-  enum { INBLK = 1 << 16 };
+  enum { INBLK = 1 << 18 };      /* read() hands over what the producer has ready, up to this much: long blocks can be shared between two decoders */
   int delay = o->decode_delay;
   if (delay < 24) {
     fprintf(err, "%s: decoder delay too small, using 200\n", o->argv0);

@@ -12,7 +12,7 @@
 static int g_chunk = 1020;      /* 68 passes of 15 steps (engine LDS15); any value works */
 /* one decoder for block-wise streaming; when ALL input is known up front (stdin is a regular file) a second decoder
  * joins and the stream is decoded in two halves at once, verified at the seam (v224hip_stream_decode_split) */
-typedef struct { void *d[2]; int len; } eng_ctx;
+typedef struct { void *d[2]; int len, holder; } eng_ctx;     /* holder: the decoder that carries the stream's state */
 static void eng_destroy(void *p) {
   eng_ctx *c = p;
   if (!c) return;
@@ -28,11 +28,20 @@ static void *eng_create(int len) {
   v224hip_set_option(c->d[0], "chunk", g_chunk);
   return c;
 }
-static int eng_init(void *h, int s) { return init_viterbi224(((eng_ctx *)h)->d[0], s); }
-static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out) {
-  return v224hip_stream_decode(((eng_ctx *)h)->d[0], syms, nbits, delay, out);
-}
+static int eng_init(void *h, int s) { eng_ctx *c = h; c->holder = 0; return init_viterbi224(c->d[0], s); }
 #define SPLIT_WARM (14 * 1020)
+#define SHARE_WARM (4 * 1020)
+/* `... | vdecode`: blocks arrive as the pipe delivers them; a long one (the producer ran ahead) is shared between two
+ * decoders, verified at the seam (v224hip_stream_decode_shared) */
+static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out) {
+  eng_ctx *c = h;
+  if (nbits >= 3 * SHARE_WARM && !c->d[1]) {
+    c->d[1] = create_viterbi224(c->len);
+    if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
+  }
+  if (!c->d[1]) return v224hip_stream_decode(c->d[c->holder], syms, nbits, delay, out);
+  return v224hip_stream_decode_shared(c->d, 2, &c->holder, syms, nbits, delay, out, SHARE_WARM);
+}
 static int eng_whole(void *h, const unsigned char *s, long long n, int d, unsigned char *o) {
   eng_ctx *c = h;
   if (n > 0x7fffffff / 2) return -1;

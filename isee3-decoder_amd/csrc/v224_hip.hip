@@ -998,11 +998,14 @@ __global__ __launch_bounds__(256) void k_count_diff(const uint4 *__restrict__ a,
 
 struct SplitItem { long long bit0; long long nbits; uint8_t *out; int snap; };   // snap: 0 none, else seam index (+ = as A, - = as B)
 
-extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
-                                           uint8_t *d_out, int warm_bits, int *nfallback) {
+// cont: decoder 0 is in the middle of a stream (no init; the block continues it); the other decoders start fresh inside the
+// block.  *holder = the decoder that stands at the end of the block with the stream's state afterwards.
+static int split_core(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
+                      uint8_t *d_out, int warm_bits, bool cont, int *nfallback, int *holder) {
   unsigned *d_cnt = nullptr, h_cnt[8] = {0};
   int rc = -1, fb = 0;
   if (nfallback) *nfallback = 0;
+  if (holder) *holder = 0;
   if (!decoders || ndec < 1 || ndec > 8 || !d_syms || !d_out || nbits < 0 || delay <= 0) {
     snprintf(g_err, sizeof g_err, "stream_decode_split: bad argument");
     return -1;
@@ -1070,7 +1073,7 @@ extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, cons
     }
     size_t it[8] = {0}; long long done[8] = {0};
     const long long slab = 8 * chunk;
-    for (int j = 0; j < P; j++) if (init_viterbi224(decoders[j], 0) != 0) goto fail;
+    for (int j = cont ? 1 : 0; j < P; j++) if (init_viterbi224(decoders[j], 0) != 0) goto fail;
     for (bool any = true; any;) {                       // slab by slab, round robin, so that the decoders' launches interleave
       any = false;
       for (int j = 0; j < P; j++) {
@@ -1113,12 +1116,57 @@ extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, cons
       HIPCHK(hipStreamSynchronize(((V224 *)decoders[j - 1])->st));
       break;
     }
+    if (holder) *holder = fb ? P - fb - 1 : P - 1;
   }
   if (nfallback) *nfallback = fb;
   rc = 0;
 fail:
   if (rc != 0) for (int j = 0; j < ndec; j++) if (decoders[j]) (void)hipStreamSynchronize(((V224 *)decoders[j])->st);
   return rc;
+}
+
+extern "C" int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *d_syms, int nbits, int delay,
+                                           uint8_t *d_out, int warm_bits, int *nfallback) {
+  return split_core(decoders, ndec, d_syms, nbits, delay, d_out, warm_bits, false, nfallback, nullptr);
+}
+
+// The next block of a stream that decoders[*holder] is in the middle of (host buffers).  A long block is shared with the
+// other decoders exactly as v224hip_stream_decode_split shares a whole stream -- they start fresh inside the block, the
+// seams are verified -- and *holder moves to the decoder that stands at the block's end; a short block simply continues on
+// the holder.  out[] is what v224hip_stream_decode() of ONE decoder fed with the same blocks would write.
+extern "C" int v224hip_stream_decode_shared(void *const *decoders, int ndec, int *holder, const uint8_t *syms, int nbits,
+                                            int delay, uint8_t *out, int warm_bits) {
+  if (!decoders || ndec < 1 || ndec > 8 || !holder || *holder < 0 || *holder >= ndec || !syms || !out || nbits < 0) {
+    snprintf(g_err, sizeof g_err, "stream_decode_shared: bad argument");
+    return -1;
+  }
+  if (nbits == 0) return 0;
+  V224 *v0 = (V224 *)decoders[*holder];
+  if (!v0) return -1;
+  const long long chunk = v0->chunk;
+  long long warm = ((long long)warm_bits + chunk - 1) / chunk * chunk;
+  const long long check = ((long long)delay + chunk - 1) / chunk * chunk;
+  if (warm < check + 2 * chunk) warm = check + 2 * chunk;
+  // worth sharing?  one decoder: n launches-worth; two: (n + warm) / 2 at the slower pair rate (23 vs 18 us) + the seam
+  if (ndec < 2 || nbits < 3 * warm) return v224hip_stream_decode(v0, syms, nbits, delay, out);
+  {
+    void *order[8];
+    int k = 0, redone = 0, h = 0;
+    order[k++] = decoders[*holder];
+    for (int i = 0; i < ndec && k < 2; i++) if (i != *holder) order[k++] = decoders[i];      // two decoders: all a CU can hold
+    HIPCHK(hipSetDevice(v0->dev));
+    HIPCHK(hipStreamSynchronize(v0->st));
+    if (ensure_cap(&v0->dsyms, &v0->dsyms_cap, 2 * (size_t)nbits) != 0 || ensure_cap(&v0->dout, &v0->dout_cap, (size_t)nbits) != 0) return -1;
+    v0->dsyms_off = v0->dsyms_cap;
+    HIPCHK(hipMemcpyAsync(v0->dsyms, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice, v0->st));
+    HIPCHK(hipStreamSynchronize(v0->st));                   // the other decoder's stream reads the symbols too
+    if (split_core(order, k, v0->dsyms, nbits, delay, v0->dout, (int)warm, true, &redone, &h) != 0) return -1;
+    HIPCHK(hipMemcpy(out, v0->dout, (size_t)nbits, hipMemcpyDeviceToHost));
+    for (int i = 0; i < ndec; i++) if (decoders[i] == order[h]) *holder = i;
+  }
+  return 0;
+fail:
+  return -1;
 }
 
 extern "C" int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, uint8_t *out) {

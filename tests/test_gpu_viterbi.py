@@ -541,3 +541,33 @@ def test_symbols_ending_at_the_last_byte_of_an_allocation(pkg, tail):
     assert d.chainback(1000, 0).tobytes() == o.chainback(1000, 0).tobytes()
     o.close()
     d.close()
+
+
+def test_stream_blocks_shared_between_two_decoders(pkg):
+    """v224hip_stream_decode_shared: a stream fed block by block, long blocks shared between the decoder that carries the
+    stream and a second one that starts fresh inside the block (seam verified): byte for byte what ONE decoder gives for
+    the same blocks -- ragged block sizes (not multiples of 15 or of the chunk), short blocks in between, the holder
+    changing hands several times, a block of pure noise (seam may fail: redone), 0xff start-up marks."""
+    delay = 200
+    nbits = 150_000
+    syms, _ = orc.gen_coded_stream(9700, nbits, 2.5, 24.0, 3)
+    rng = np.random.default_rng(4)
+    syms[2 * 70_000:2 * 88_000] = rng.integers(0, 256, 36_000, dtype=np.uint8)        # 18 000 bits of noise
+    one = pkg.Viterbi224(delay + 2 * 1020)
+    one.init(0)
+    decs = [pkg.Viterbi224(delay + 2 * 1020) for _ in range(2)]
+    decs[0].init(0)
+    holder, pos, holders = 0, 0, []
+    for n in (511, 13_001, 1, 25_000, 40, 12_240, 30_000, 19_999, 9_000, 16_384, 23_824):
+        blk = syms[2 * pos:2 * (pos + n)]
+        want = one.stream_decode(blk, delay)
+        got, holder = pkg.stream_decode_shared(decs, holder, blk, delay, 4080)
+        assert np.array_equal(got, want), "block at bit %d (%d bits)" % (pos, n)
+        holders.append(holder)
+        pos += n
+    assert pos == nbits and len(set(holders)) == 2              # the stream really changed hands
+    # afterwards the holder continues through the plain API like any decoder
+    tail, _ = orc.gen_coded_stream(9701, 600, 3.0, 24.0, 0)
+    assert np.array_equal(decs[holder].stream_decode(tail, delay), one.stream_decode(tail, delay))
+    for d in decs + [one]:
+        d.close()
