@@ -58,7 +58,7 @@ int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *
                                 uint8_t *d_out, int warm_bits, int *nfallback);
 
 /* Streaming form of the same sharing, host buffers: the next block of a stream that decoders[*holder] is in the middle
- * of.  A block of at least three warm-ups is shared between the holder and one other decoder (which starts fresh inside
+ * of.  A block of at least 2.2 warm-ups is shared between the holder and one other decoder (which starts fresh inside
  * the block; seam verified as above, redone by the holder's side if it fails) and *holder moves to the decoder that
  * stands at the end of the block; a shorter block just continues on the holder.  Feeding a stream block by block
  * through this call gives exactly the output of v224hip_stream_decode() on one decoder.  Start with init_viterbi224 on

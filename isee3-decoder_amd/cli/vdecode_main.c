@@ -30,12 +30,12 @@ static void *eng_create(int len) {
 }
 static int eng_init(void *h, int s) { eng_ctx *c = h; c->holder = 0; return init_viterbi224(c->d[0], s); }
 #define SPLIT_WARM (14 * 1020)
-#define SHARE_WARM (4 * 1020)
+#define SHARE_WARM (3 * 1020)       /* one chunk of seam window + 2 040 bits of forgetting (chain_core.c: why) */
 /* `... | vdecode`: blocks arrive as the pipe delivers them; a long one (the producer ran ahead) is shared between two
  * decoders, verified at the seam (v224hip_stream_decode_shared) */
 static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out) {
   eng_ctx *c = h;
-  if (nbits >= 3 * SHARE_WARM && !c->d[1]) {
+  if (5 * nbits >= 11 * SHARE_WARM && !c->d[1]) {
     c->d[1] = create_viterbi224(c->len);
     if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
   }

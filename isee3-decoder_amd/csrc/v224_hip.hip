@@ -1147,8 +1147,9 @@ extern "C" int v224hip_stream_decode_shared(void *const *decoders, int ndec, int
   long long warm = ((long long)warm_bits + chunk - 1) / chunk * chunk;
   const long long check = ((long long)delay + chunk - 1) / chunk * chunk;
   if (warm < check + 2 * chunk) warm = check + 2 * chunk;
-  // worth sharing?  one decoder: n launches-worth; two: (n + warm) / 2 at the slower pair rate (23 vs 18 us) + the seam
-  if (ndec < 2 || nbits < 3 * warm) return v224hip_stream_decode(v0, syms, nbits, delay, out);
+  // worth sharing?  one decoder: n steps at 18 us per 15; two: (n + warm) / 2 steps each at the pair rate (23 us per 15) + the
+  // seam (two 16 MiB snapshots, one compare, ~0.15 ms): break-even near n = 2 warm
+  if (ndec < 2 || 5LL * nbits < 11 * warm) return v224hip_stream_decode(v0, syms, nbits, delay, out);
   {
     void *order[8];
     int k = 0, redone = 0, h = 0;

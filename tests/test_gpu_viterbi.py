@@ -543,7 +543,8 @@ def test_symbols_ending_at_the_last_byte_of_an_allocation(pkg, tail):
     d.close()
 
 
-def test_stream_blocks_shared_between_two_decoders(pkg):
+@pytest.mark.parametrize("chunk,warms", [(1020, (3060, 4080)), (510, (1530, 1530))], ids=["chunk1020", "chunk510_as_the_chain"])
+def test_stream_blocks_shared_between_two_decoders(pkg, chunk, warms):
     """v224hip_stream_decode_shared: a stream fed block by block, long blocks shared between the decoder that carries the
     stream and a second one that starts fresh inside the block (seam verified): byte for byte what ONE decoder gives for
     the same blocks -- ragged block sizes (not multiples of 15 or of the chunk), short blocks in between, the holder
@@ -556,12 +557,14 @@ def test_stream_blocks_shared_between_two_decoders(pkg):
     one = pkg.Viterbi224(delay + 2 * 1020)
     one.init(0)
     decs = [pkg.Viterbi224(delay + 2 * 1020) for _ in range(2)]
+    for d in decs + [one]:
+        d.set_option("chunk", chunk)
     decs[0].init(0)
     holder, pos, holders = 0, 0, []
-    for n in (511, 13_001, 1, 25_000, 40, 12_240, 30_000, 19_999, 9_000, 16_384, 23_824):
+    for n in (511, 13_001, 1, 25_000, 40, 12_240, 30_000, 19_999, 9_000, 3_384, 36_824):
         blk = syms[2 * pos:2 * (pos + n)]
         want = one.stream_decode(blk, delay)
-        got, holder = pkg.stream_decode_shared(decs, holder, blk, delay, 4080)
+        got, holder = pkg.stream_decode_shared(decs, holder, blk, delay, warms[0] if pos < 60_000 else warms[1])
         assert np.array_equal(got, want), "block at bit %d (%d bits)" % (pos, n)
         holders.append(holder)
         pos += n
