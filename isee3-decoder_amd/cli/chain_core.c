@@ -116,8 +116,7 @@ static void sy_destroy(void *p) {
 }
 
 /* stream chunk of the decoders (bits): read from the environment ONCE, before any chain thread exists */
-/* 510 = 34 passes of 15: the seam window of a shared block is the decode delay rounded up to whole chunks */
-#define CHAIN_CHUNK 510
+#define CHAIN_CHUNK 1020            /* 68 passes of 15 */
 static int g_chunk = CHAIN_CHUNK;
 static pthread_once_t g_chunk_once = PTHREAD_ONCE_INIT;
 static void chunk_from_env(void) {
@@ -127,7 +126,8 @@ static void chunk_from_env(void) {
 }
 /* vdecode engine: one decoder for block-wise streaming; for one long stream (whole-input mode) a second decoder joins
  * and the stream is decoded in two halves at once, verified at the seam (v224hip_stream_decode_split) */
-typedef struct { void *d[2]; int len, holder; } vd_ctx;      /* holder: the decoder that carries the stream's state */
+typedef struct { void *d[2]; int len, holder; volatile int *front_done; } vd_ctx;   /* holder: the decoder that carries the stream's state */
+static __thread volatile int *t_front_done;      /* set by the chain for its vdecode thread: 1 once symdemod has finished */
 /* Viterbi decoders (2.2 GiB decision ring, placement probe) are kept between calls too: a few, so that concurrent
  * chains each find one. */
 #define VD_POOL 4
@@ -174,23 +174,28 @@ static void *vd_create(int len) {
   v224hip_set_option(c->d[0], "chunk", g_chunk);
   return c;
 }
-static int vd_init(void *h, int s) { vd_ctx *c = h; c->holder = 0; return init_viterbi224(c->d[0], s); }
+static int vd_init(void *h, int s) { vd_ctx *c = h; c->holder = 0; c->front_done = t_front_done; return init_viterbi224(c->d[0], s); }
 #define VD_SPLIT_WARM (4 * 1020)
 /* warm-up of a decoder that joins inside a block: one chunk of seam window (>= the decode delay) + 1 020 bits for its fresh
  * start to be forgotten.  Measured (profiles/r02h_metric_convergence.txt): all 2^23 path metrics agree with those of a
  * decoder that followed the stream from its beginning after <= 255 steps at Eb/N0 3 dB, <= 390 at 1.5 dB, <= 765 at 0 dB;
  * on pure noise only after ~3 000 -- there the seam check fails and the block is finished by the first decoder alone. */
-#define VD_SHARE_WARM (3 * CHAIN_CHUNK)
-/* one block of the stream.  When the stages in front run ahead (they do: the Viterbi is the slowest), blocks get long, and
- * a long block is shared between two decoders (v224hip_stream_decode_shared: the second one starts fresh inside the
- * block, verified at the seam): same bits, two launch chains on the GPU instead of one. */
+#define VD_SHARE_WARM (3 * CHAIN_CHUNK)      /* 1 020 + 2 040 */
+/* one block of the stream.  The stages in front run ahead (the Viterbi is the slowest), so blocks get long, and a long
+ * block can be shared between two decoders (v224hip_stream_decode_shared: the second one starts fresh inside the block,
+ * verified at the seam): same bits, two launch chains on the GPU instead of one.  But two 1024-thread workgroups per CU
+ * are ALL the wave slots a CU has: while pmdemod / symdemod still have kernels to run, a second decoder starves them
+ * (measured: front-end 13 -> 50 ms, chain 40 -> 54 ms).  So a block is shared only once the front end has finished --
+ * typically the last, longest block.  ISEE3_CHAIN_SHARE=0 never shares, =2 shares whenever a block is long enough. */
 static int vd_stream_any(vd_ctx *c, const unsigned char *s, int n, int d, unsigned char *o) {
-  if (5 * n >= 11 * VD_SHARE_WARM && !c->d[1] && !(getenv("ISEE3_CHAIN_SHARE") && !atoi(getenv("ISEE3_CHAIN_SHARE")))) {
+  const char *e = getenv("ISEE3_CHAIN_SHARE");
+  const int mode = e ? atoi(e) : 1;
+  const int may = mode == 2 || (mode == 1 && c->front_done && *c->front_done);
+  if (may && 5 * n >= 11 * VD_SHARE_WARM && !c->d[1]) {
     c->d[1] = create_viterbi224(c->len);
     if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
   }
-  if (!c->d[1] || (getenv("ISEE3_CHAIN_SHARE") && !atoi(getenv("ISEE3_CHAIN_SHARE"))))
-    return v224hip_stream_decode(c->d[c->holder], s, n, d, o);
+  if (!may || !c->d[1]) return v224hip_stream_decode(c->d[c->holder], s, n, d, o);
   return v224hip_stream_decode_shared(c->d, 2, &c->holder, s, n, d, o, VD_SHARE_WARM);
 }
 static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) { TIMED(vd_stream_any(h, s, n, d, o)); }
@@ -340,8 +345,8 @@ static int iq_next(void *p, int N, const int16_t **blk, int *is_dev) {
 }
 
 typedef struct { pmdemod_opts o; iq_src src; blkchan *out; int rc; double ms; } pm_arg;
-typedef struct { symdemod_opts o; blkchan *in; FILE *out; int rc; double ms; } sy_arg;
-typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; } vd_arg;
+typedef struct { symdemod_opts o; blkchan *in; FILE *out; int rc; double ms; volatile int *done; } sy_arg;
+typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; volatile int *front_done; } vd_arg;
 
 static void *pm_thread(void *p) {
   pm_arg *a = p;
@@ -360,6 +365,7 @@ static void *sy_thread(void *p) {
   t_stage_ms = 0;
   a->rc = symdemod_run_blk(&a->o, &e, blk_next, a->in, a->out, stderr);
   a->ms = t_stage_ms;
+  __atomic_store_n(a->done, 1, __ATOMIC_RELEASE);    /* before the pipe closes: what vdecode reads from now on is all there is */
   fclose(a->out);
   blk_reader_gone(a->in);
   return NULL;
@@ -369,6 +375,7 @@ static void *vd_thread(void *p) {
   vdecode_result r;
   vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk, vd_whole };
   t_stage_ms = 0;
+  t_front_done = a->front_done;
   a->rc = vdecode_run(&a->o, &e, a->fd_in, a->out, stderr, &r);
   a->ms = t_stage_ms;
   fflush(a->out);
@@ -407,9 +414,10 @@ static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   fcntl(p2[1], F_SETPIPE_SZ, 1 << 20);
 #endif
   blk_init(&c1);
+  volatile int front_done = 0;
   pa.src = *src; pa.out = &c1;
-  sa.in = &c1; sa.out = fdopen(p2[1], "w");
-  va.fd_in = p2[0]; va.out = out;
+  sa.in = &c1; sa.out = fdopen(p2[1], "w"); sa.done = &front_done;
+  va.fd_in = p2[0]; va.out = out; va.front_done = &front_done;
   pthread_t t1, t2, t3;
   pthread_create(&t1, NULL, pm_thread, &pa);
   pthread_create(&t2, NULL, sy_thread, &sa);

@@ -31,11 +31,13 @@ static void *eng_create(int len) {
 static int eng_init(void *h, int s) { eng_ctx *c = h; c->holder = 0; return init_viterbi224(c->d[0], s); }
 #define SPLIT_WARM (14 * 1020)
 #define SHARE_WARM (3 * 1020)       /* one chunk of seam window + 2 040 bits of forgetting (chain_core.c: why) */
-/* `... | vdecode`: blocks arrive as the pipe delivers them; a long one (the producer ran ahead) is shared between two
- * decoders, verified at the seam (v224hip_stream_decode_shared) */
+/* `... | vdecode`: blocks arrive as the pipe delivers them.  With VDECODE_SHARE=1 a long one (the producer ran ahead) is
+ * shared between two decoders, verified at the seam (v224hip_stream_decode_shared).  Off by default: two decoders take
+ * every wave slot of every CU, and a pmdemod / symdemod feeding this pipe from the same GPU would starve. */
+static int g_share;
 static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, unsigned char *out) {
   eng_ctx *c = h;
-  if (5 * nbits >= 11 * SHARE_WARM && !c->d[1]) {
+  if (g_share && 5 * nbits >= 11 * SHARE_WARM && !c->d[1]) {
     c->d[1] = create_viterbi224(c->len);
     if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
   }
@@ -69,6 +71,7 @@ int main(int argc, char **argv) {
   int chunk = getenv("V224HIP_CHUNK") ? atoi(getenv("V224HIP_CHUNK")) : 1020;
   if (chunk < 1) chunk = 1020;
   g_chunk = chunk;
+  g_share = getenv("VDECODE_SHARE") && atoi(getenv("VDECODE_SHARE"));
   vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 2 * chunk, eng_whole };
   {
     struct stat sb;                                        /* a file on stdin: all input is there, nobody waits for early bits */

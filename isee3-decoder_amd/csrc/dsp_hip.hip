@@ -58,6 +58,22 @@ static int grow(void **p, size_t *cap, size_t need) {
   return 0;
 }
 
+// Small results and index tables travel through pinned, device-mapped host memory: kernels store scalars / short arrays
+// straight into it (no copy command at all), and what has to be copied (index tables up, a flag down) is a truly
+// asynchronous DMA instead of the staged, blocking copy a pageable buffer gets.  One stream synchronise per engine call.
+struct Pin { void *h, *d; size_t cap; };
+static int pin_grow(Pin *p, size_t need) {
+  if (p->cap >= need) return 0;
+  if (p->h) (void)hipHostFree(p->h);
+  p->h = p->d = nullptr; p->cap = 0;
+  if (need < 4096) need = 4096;
+  if (hipHostMalloc(&p->h, need, hipHostMallocMapped) != hipSuccess) { p->h = nullptr; return -1; }
+  if (hipHostGetDevicePointer(&p->d, p->h, 0) != hipSuccess) { (void)hipHostFree(p->h); p->h = nullptr; return -1; }
+  p->cap = need;
+  return 0;
+}
+static void pin_free(Pin *p) { if (p->h) (void)hipHostFree(p->h); p->h = p->d = nullptr; p->cap = 0; }
+
 // ===========================================================================================
 // symdemod
 // ===========================================================================================
@@ -77,6 +93,7 @@ struct Symd {
   void *d_terms; size_t terms_cap;
   unsigned *d_flag;
   int inexact_last;                          // the previous window's sums left the exactly-representable range
+  Pin pin_idx, pin_e, pin_out, pin_hdr;      // index table staging; energies, symbols, {flags, energy sum} written by kernels
 };
 
 __device__ __forceinline__ long long wave_incl_scan(long long v) {
@@ -256,7 +273,15 @@ __global__ __launch_bounds__(256) void k_timesearch_fin(const unsigned long long
   int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= noff) return;
   unsigned long long acc = 0; unsigned bad = 0;
-  for (int s = 0; s < nslices; s++) { acc += part[(size_t)s * noff + t]; if (acc >= TS_LIMIT) bad = 1; }
+  int s = 0;
+  for (; s + 8 <= nslices; s += 8) {                  // eight independent loads in flight, then the ordered overflow checks
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = part[(size_t)(s + u) * noff + t];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { acc += v[u]; if (acc >= TS_LIMIT) bad = 1; }
+  }
+  for (; s < nslices; s++) { acc += part[(size_t)s * noff + t]; if (acc >= TS_LIMIT) bad = 1; }
   energies[t] = (double)acc;
   if (bad) atomicOr(inexact, 1u);
 }
@@ -337,6 +362,7 @@ extern "C" void symd_destroy(void *p) {
   (void)hipFree(h->d_s); (void)hipFree(h->d_s2); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
   (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym); (void)hipFree(h->d_part); (void)hipFree(h->d_terms);
   (void)hipFree(h->d_flag);
+  pin_free(&h->pin_idx); pin_free(&h->pin_e); pin_free(&h->pin_out); pin_free(&h->pin_hdr);
   free(h);
 }
 // ---- the window buffer kept in HBM (symdemod.c:96-125 without the host copy) ----
@@ -414,12 +440,15 @@ extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks,
       return -1;
     }
     CHK(hipSetDevice(h->dev));
-    if (grow(&h->d_idx, &h->idx_cap, sizeof(int) * (size_t)nsw) || grow(&h->d_e, &h->e_cap, sizeof(double) * (size_t)noff)) {
+    if (grow(&h->d_idx, &h->idx_cap, sizeof(int) * (size_t)nsw) || pin_grow(&h->pin_idx, sizeof(int) * (size_t)nsw) ||
+        pin_grow(&h->pin_e, sizeof(double) * (size_t)noff) || pin_grow(&h->pin_hdr, 64)) {
       snprintf(g_err, sizeof g_err, "symd_timesearch: allocation failed");
       return -1;
     }
-    CHK(hipMemcpyAsync(h->d_idx, sw, sizeof(int) * (size_t)nsw, hipMemcpyHostToDevice, h->st));
+    memcpy(h->pin_idx.h, sw, sizeof(int) * (size_t)nsw);
+    CHK(hipMemcpyAsync(h->d_idx, h->pin_idx.h, sizeof(int) * (size_t)nsw, hipMemcpyHostToDevice, h->st));
     const int nslices = (nsymbols + TS_SLICE - 1) / TS_SLICE;
+    volatile unsigned *hflag = (volatile unsigned *)h->pin_hdr.h;
     unsigned flag = 1;
     // the exact-integer parallel form first -- unless the previous window already left its range (it then will again:
     // at 10 MS/s one symbol spans 9 760 samples and the window total passes 2^53)
@@ -428,20 +457,21 @@ extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks,
       k_timesearch_part<<<dim3((noff + 255) / 256, nslices), 256, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks,
                                                                             nsymbols, noff, (unsigned long long *)h->d_part, h->d_flag);
       k_timesearch_fin<<<(noff + 255) / 256, 256, 0, h->st>>>((const unsigned long long *)h->d_part, nslices, noff,
-                                                            (double *)h->d_e, h->d_flag);
-      CHK(hipMemcpyAsync(&flag, h->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, h->st));
-      CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
+                                                            (double *)h->pin_e.d, h->d_flag);
+      CHK(hipMemcpyAsync(h->pin_hdr.h, h->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, h->st));
       CHK(hipStreamSynchronize(h->st));
+      flag = *hflag;
     }
     // remember it for the next windows, and look again every 32nd (a capture may change level)
     h->inexact_last = flag ? (h->inexact_last % 32) + 1 : 0;
     if (h->inexact_last == 32 || getenv("ISEE3DSP_RETRY_EXACT")) h->inexact_last = 0;
     if (flag) {     // some sum left the exactly-representable range: the reference's own order of additions
       k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks, nsymbols,
-                                                       noff, (double *)h->d_e);
-      CHK(hipMemcpyAsync(energies, h->d_e, sizeof(double) * (size_t)noff, hipMemcpyDeviceToHost, h->st));
+                                                       noff, (double *)h->pin_e.d);
+      CHK(hipGetLastError());
       CHK(hipStreamSynchronize(h->st));
     }
+    memcpy(energies, h->pin_e.h, sizeof(double) * (size_t)noff);
   }
   return 0;
 fail:
@@ -459,28 +489,29 @@ extern "C" int symd_demod(void *p, const int *edges, int symbolclocks, int nsymb
     }
     CHK(hipSetDevice(h->dev));
     if (grow(&h->d_idx, &h->idx_cap, sizeof(int) * (size_t)ne) || grow(&h->d_sym, &h->sym_cap, sizeof(long long) * (size_t)nsymbols) ||
-        grow(&h->d_out, &h->out_cap, (size_t)nsymbols) || grow(&h->d_e, &h->e_cap, sizeof(double))) {
+        pin_grow(&h->pin_idx, sizeof(int) * (size_t)ne) || pin_grow(&h->pin_out, (size_t)nsymbols) || pin_grow(&h->pin_hdr, 64)) {
       snprintf(g_err, sizeof g_err, "symd_demod: allocation failed");
       return -1;
     }
-    CHK(hipMemcpyAsync(h->d_idx, edges, sizeof(int) * (size_t)ne, hipMemcpyHostToDevice, h->st));
-    uint8_t *dst = (out && out_is_dev) ? out : (uint8_t *)h->d_out;
+    memcpy(h->pin_idx.h, edges, sizeof(int) * (size_t)ne);
+    CHK(hipMemcpyAsync(h->d_idx, h->pin_idx.h, sizeof(int) * (size_t)ne, hipMemcpyHostToDevice, h->st));
+    // symbols, energy sum and its flag are stored by the kernels straight into mapped host memory
+    uint8_t *dst = (out && out_is_dev) ? out : (uint8_t *)h->pin_out.d;
+    double *d_esum = (double *)((char *)h->pin_hdr.d + 16);
+    unsigned *d_eflag = (unsigned *)((char *)h->pin_hdr.d + 8);
     k_demod<<<(nsymbols + 255) / 256, 256, 0, h->st>>>(h->d_P, (const int *)h->d_idx, symbolclocks, nsymbols, gain,
                                                        (gain != 0 && out) ? dst : nullptr, (long long *)h->d_sym);
-    unsigned flag = 0;
-    if (energy_sum) {
-      k_par_energy<<<1, 256, 0, h->st>>>((const long long *)h->d_sym, nsymbols, (double *)h->d_e, h->d_flag + 1);
-      CHK(hipMemcpyAsync(energy_sum, h->d_e, sizeof(double), hipMemcpyDeviceToHost, h->st));
-      CHK(hipMemcpyAsync(&flag, h->d_flag + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->st));
-    }
-    if (gain != 0 && out && !out_is_dev)
-      CHK(hipMemcpyAsync(out, h->d_out, (size_t)nsymbols, hipMemcpyDeviceToHost, h->st));
+    if (energy_sum) k_par_energy<<<1, 256, 0, h->st>>>((const long long *)h->d_sym, nsymbols, d_esum, d_eflag);
+    CHK(hipGetLastError());
     CHK(hipStreamSynchronize(h->st));
-    if (energy_sum && (flag || getenv("ISEE3DSP_SEQUENTIAL"))) {
-      k_seq_energy<<<1, 64, 0, h->st>>>((const long long *)h->d_sym, nsymbols, (double *)h->d_e);
-      CHK(hipMemcpyAsync(energy_sum, h->d_e, sizeof(double), hipMemcpyDeviceToHost, h->st));
-      CHK(hipStreamSynchronize(h->st));
+    if (energy_sum) {
+      if (*(volatile unsigned *)((char *)h->pin_hdr.h + 8) || getenv("ISEE3DSP_SEQUENTIAL")) {
+        k_seq_energy<<<1, 64, 0, h->st>>>((const long long *)h->d_sym, nsymbols, d_esum);
+        CHK(hipStreamSynchronize(h->st));
+      }
+      *energy_sum = *(volatile double *)((char *)h->pin_hdr.h + 16);
     }
+    if (gain != 0 && out && !out_is_dev) memcpy(out, h->pin_out.h, (size_t)nsymbols);
   }
   return 0;
 fail:
@@ -501,6 +532,7 @@ struct Pmd {
   void *d_red; size_t red_cap;           // reduction scratch
   int16_t *d_out16; double *d_pre;
   int have_lo;
+  Pin pin_hdr;                           // peak record @0, spin-down sum @128, variance sum @144: written by the kernels
 };
 
 __global__ __launch_bounds__(256) void k_twiddles(double2 *tw, int N) {
@@ -908,6 +940,7 @@ extern "C" void *pmd_create(int fftsize) {
   CHK(hipMalloc(&h->d_pre, sizeof(double) * (size_t)fftsize));
   h->red_cap = sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak) + sizeof(PeakRec) * RED_BLOCKS;
   CHK(hipMalloc(&h->d_red, h->red_cap));
+  if (pin_grow(&h->pin_hdr, 256) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: pinned mailbox"); goto fail; }
   if (lg >= 12 && !getenv("ISEE3DSP_FFT_REGISTER_RADIX")) {
     FftCtx c;
     if (fft_tables(&c, fftsize, &h->twA, &h->twB, &h->twR, h->st) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: twiddle tables"); goto fail; }
@@ -931,6 +964,7 @@ extern "C" void pmd_destroy(void *p) {
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red);
+  pin_free(&h->pin_hdr);
   free(h);
 }
 // de-chirp LO table (N complex doubles = the lophase sequence of pmdemod.c:237-243, computed by the
@@ -1002,14 +1036,14 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
       }
     }
     PeakRec *part = (PeakRec *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak));
-    pmd_peak *dres = (pmd_peak *)((char *)h->d_red + sizeof(double2) * (RED_BLOCKS + 64));
     int nb = (lastbin - firstbin + 255) / 256;
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     if (nb < 1) nb = 1;
     k_peak_partial<<<nb, 256, 0, h->st>>>(h->spec, firstbin, lastbin, part);
-    k_peak_final<<<1, 256, 0, h->st>>>(part, nb, h->spec, h->N, dres);
-    CHK(hipMemcpyAsync(out, dres, sizeof(pmd_peak), hipMemcpyDeviceToHost, h->st));
+    k_peak_final<<<1, 256, 0, h->st>>>(part, nb, h->spec, h->N, (pmd_peak *)h->pin_hdr.d);      // straight into mapped host memory
+    CHK(hipGetLastError());
     CHK(hipStreamSynchronize(h->st));
+    memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
   }
   return 0;
 fail:
@@ -1027,22 +1061,24 @@ extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *ou
     const short2 *iq = (const short2 *)h->cur_iq;
     const double2 *lo = h->have_lo ? h->lo : nullptr;
     int nb = (h->N + 255) / 256; if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    (void)tot;
     k_mix<<<nb, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, part);
-    k_sum2<<<1, 256, 0, h->st>>>(part, nb, tot);
+    k_sum2<<<1, 256, 0, h->st>>>(part, nb, (double2 *)((char *)h->pin_hdr.d + 128));
     double2 dc;
-    CHK(hipMemcpyAsync(&dc, tot, sizeof dc, hipMemcpyDeviceToHost, h->st));
+    CHK(hipGetLastError());
     CHK(hipStreamSynchronize(h->st));
+    { const volatile double *m = (const volatile double *)((char *)h->pin_hdr.h + 128); dc.x = m[0]; dc.y = m[1]; }
     double dcr = dc.x / h->N, dci = dc.y / h->N;
     double amp = hypot(dcr, dci);                 // cabs, pmdemod.c:337
     double ur = dcr / amp, ui = -dci / amp;       // conj(dc) / amp, :338
     int16_t *o16 = (out16 && out_is_dev) ? out16 : h->d_out16;
     double *opre = pre ? (out_is_dev ? pre : h->d_pre) : nullptr;
     k_rotate<<<nb, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, ur, ui, amp, o16, opre, part);
-    k_sum2<<<1, 256, 0, h->st>>>(part, nb, tot);
-    CHK(hipMemcpyAsync(&dc, tot, sizeof dc, hipMemcpyDeviceToHost, h->st));
+    k_sum2<<<1, 256, 0, h->st>>>(part, nb, (double2 *)((char *)h->pin_hdr.d + 144));
     if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
     if (pre && !out_is_dev) CHK(hipMemcpyAsync(pre, h->d_pre, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
     CHK(hipStreamSynchronize(h->st));
+    { const volatile double *m = (const volatile double *)((char *)h->pin_hdr.h + 144); dc.x = m[0]; dc.y = m[1]; }
     res->dc_re = dcr; res->dc_im = dci; res->amplitude = amp; res->diffsumsq = dc.x / h->N;
   }
   return 0;

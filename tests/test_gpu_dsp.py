@@ -299,6 +299,18 @@ def test_vdecode_cli_file_input_uses_both_decoders_same_output(pkg, tmp_path):
     assert len(piped.stdout) > 99_000 and piped.stdout == filed.stdout
 
 
+def test_vdecode_cli_pipe_mode_shared_blocks_same_output(pkg):
+    """`cat file | VDECODE_SHARE=1 vdecode`: long blocks shared between two decoders == the plain pipe mode, byte for byte"""
+    nbits = 120_000
+    syms, _ = orc.gen_coded_stream(9510, nbits, 3.0, 24.0, 2)
+    exe = pkg.cli_path("vdecode")
+    plain = subprocess.run([exe, "-q"], input=syms.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    shared = subprocess.run([exe, "-q"], input=syms.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                            env=dict(os.environ, VDECODE_SHARE="1"))
+    assert plain.returncode == 0 and shared.returncode == 0, shared.stderr
+    assert len(plain.stdout) > 119_000 and plain.stdout == shared.stdout
+
+
 def test_chain_objects_are_reused_and_released(pkg):
     """libisee3chain.so keeps its decoder / pmdemod / symdemod objects between calls (a kept pmdemod handle must not
     carry the previous call's de-chirp table or state): three calls, two settings, same answers as fresh; then release."""
