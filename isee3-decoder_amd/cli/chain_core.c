@@ -199,6 +199,12 @@ static int vd_stream_any(vd_ctx *c, const unsigned char *s, int n, int d, unsign
   return v224hip_stream_decode_shared(c->d, 2, &c->holder, s, n, d, o, VD_SHARE_WARM);
 }
 static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned char *o) { TIMED(vd_stream_any(h, s, n, d, o)); }
+/* while the front end is still producing, take the symbols in blocks of at most eight windows: the moment it finishes
+ * is then noticed within a few ms, and everything that is left goes to two decoders as ONE long block */
+static unsigned long vd_read_limit(void *h) {
+  vd_ctx *c = h;
+  return (c->front_done && !*c->front_done) ? 8192ul : 0ul;
+}
 static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigned char *o) {
   vd_ctx *c = h;
   if (n > 0x7fffffff / 2) return -1;
@@ -373,7 +379,7 @@ static void *sy_thread(void *p) {
 static void *vd_thread(void *p) {
   vd_arg *a = p;
   vdecode_result r;
-  vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk, vd_whole };
+  vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk, vd_whole, vd_read_limit };
   t_stage_ms = 0;
   t_front_done = a->front_done;
   a->rc = vdecode_run(&a->o, &e, a->fd_in, a->out, stderr, &r);

@@ -157,7 +157,10 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
 
   if (!whole) {
     for (;;) {
-      ssize_t got = read(fd_in, inbuf, INBLK);
+      unsigned long want = e->read_limit ? e->read_limit(vd) : 0;
+      if (want == 0 || want > INBLK) want = INBLK;
+      if (want < 2) want = 2;
+      ssize_t got = read(fd_in, inbuf, want);
       if (got <= 0) break;
       size_t nfl = 0, f = 0;
       size_t np = pass1(o, &s1, inbuf, (size_t)got, delay, syms, hard, 0, fl, &nfl);

@@ -30,6 +30,9 @@ typedef struct {
   int   ring_extra;      /* rows the engine needs beyond decode_delay */
   /* optional (may be NULL): the same contract as stream_decode for one long stream right after init */
   int   (*stream_decode_whole)(void *h, const unsigned char *syms, long long nbits, int delay, unsigned char *out);
+  /* optional (may be NULL): how many input bytes the next read() may take at most (0 = no preference).  An engine that
+     wants to look at its surroundings between blocks keeps them short for a while. */
+  unsigned long (*read_limit)(void *h);
 } vdecode_engine;
 
 typedef struct {

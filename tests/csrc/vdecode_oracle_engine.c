@@ -22,12 +22,13 @@ static int eng_whole(void *h, const unsigned char *syms, long long nbits, int de
   return eng_stream(h, syms, (int)nbits, delay, out);
 }
 static void eng_destroy(void *h) { orc_v224_delete(h); }
+static unsigned long eng_limit(void *h) { (void)h; return getenv("VDECODE_TEST_LIMIT") ? strtoul(getenv("VDECODE_TEST_LIMIT"), NULL, 10) : 0; }
 
 int main(int argc, char **argv) {
   vdecode_opts o;
   vdecode_result r;
   vdecode_parse_args(&o, argc, argv);
-  vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 0, eng_whole };
+  vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 0, eng_whole, eng_limit };
   o.whole_input = getenv("VDECODE_WHOLE") && atoi(getenv("VDECODE_WHOLE"));
   int rc = vdecode_run(&o, &e, 0, stdout, stderr, &r);
   fprintf(stderr, "RESULT bits=%llu symerrs=%llu flips=%d\n", r.bits_out, r.symerrs_total, r.flips);

@@ -34,7 +34,7 @@ def harness():
     return exe
 
 
-@pytest.mark.parametrize("whole", ["0", "1"], ids=["blockwise", "whole_input"])
+@pytest.mark.parametrize("whole", ["0", "1", "limit"], ids=["blockwise", "whole_input", "blockwise_read_limit_777"])
 @pytest.mark.parametrize("name", _names())
 def test_host_logic_with_oracle_engine(harness, name, whole):
     """block by block as the input arrives (the reference's way), or pass 1 over ALL input first and one engine call
@@ -42,7 +42,8 @@ def test_host_logic_with_oracle_engine(harness, name, whole):
     z = np.load(G)
     p = subprocess.run([harness, "-q"] + _args(z, name), input=z[name + "/syms"].tobytes(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600,
-                       env=dict(os.environ, VDECODE_WHOLE=whole))
+                       env=dict(os.environ, VDECODE_WHOLE="1" if whole == "1" else "0",
+                                **({"VDECODE_TEST_LIMIT": "777"} if whole == "limit" else {})))
     assert p.stdout == z[name + "/stdout"].tobytes()
     if name == "flip":
         assert b"flips=1" in p.stderr
