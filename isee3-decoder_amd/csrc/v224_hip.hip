@@ -507,6 +507,13 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : 1020);   // whole passes per chunk (1020 = 68 x 15)
   HIPCHK(hipSetDevice(v->dev));
   if (v->engine == V224HIP_ENGINE_LDS15) {       // 133 KiB of dynamic LDS per workgroup: above the default cap
+    static bool tab_done[64] = {false};
+    if (v->dev >= 0 && v->dev < 64 && !tab_done[v->dev]) {     // the per-thread parity table of the 15-step kernel, once per device
+      std::vector<unsigned> tab(4 * 1024);
+      l15_build_rot_tab(tab.data());
+      HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(l15_rot_tab), tab.data(), tab.size() * sizeof(unsigned)));
+      tab_done[v->dev] = true;
+    }
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
