@@ -32,6 +32,9 @@ import time
 
 import numpy as np
 
+# read by the HIP runtime when it initialises (torch does that first here): see csrc/v224_hip.hip, isee3_more_hw_queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 ALG_BYTES_PER_STEP = (1 << 23) * 2 * 2 + (1 << 23) // 8          # read + write u16 metrics + decisions
 HBM_PEAK_GBS = 8000.0

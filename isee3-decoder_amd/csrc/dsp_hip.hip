@@ -22,6 +22,14 @@
 extern "C" void pmd_carrier_params(double cstep, uint64_t *u_hi, uint64_t *u_lo, double *logrho);
 #pragma GCC visibility pop
 
+// HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one run their
+// kernels in order.  A decoder has two streams (trellis passes / tracebacks), a stream shared by two decoders needs four
+// that really run side by side, the chain adds its front-end stages: with 4 queues it depends on the process's history
+// whether two of them collide (measured: one stream on two decoders 2.40 instead of 2.55 Msymbols/s, the chain 364
+// instead of 425 Msamples/s).  The variable is read when the HIP runtime initialises, i.e. at the first HIP call of the
+// process: this runs when the library is loaded, and only sets it if the user has not.
+__attribute__((constructor)) static void isee3_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 static thread_local char g_err[512] = "";
 static int g_device = -1;
 extern "C" const char *isee3dsp_last_error(void) { return g_err; }
@@ -48,6 +56,19 @@ extern "C" void *isee3dsp_dev_alloc(size_t bytes) {
 extern "C" void isee3dsp_dev_free(void *d) { if (d) (void)hipFree(d); }
 extern "C" int isee3dsp_h2d(void *d, const void *h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int isee3dsp_d2h(void *h, const void *d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+
+// The front-end kernels are short and their results are waited for by the host; the Viterbi decoder of the same process
+// enqueues hundreds of 18 us launches ahead.  HIP maps streams onto a handful of hardware queues round robin, and a DSP
+// stream that lands on the decoder's queue waits behind all of them (measured: pmdemod 7 -> 38 ms per capture, depending
+// on how many streams the process had created before).  Streams of the highest priority get queues of their own and
+// are dispatched first.
+static hipError_t dsp_stream_create(hipStream_t *st) {
+  int least = 0, greatest = 0;
+  if (!getenv("ISEE3DSP_NORMAL_PRIORITY") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+      hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+  (void)hipGetLastError();
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 
 static int grow(void **p, size_t *cap, size_t need) {
   if (*cap >= need) return 0;
@@ -342,7 +363,7 @@ extern "C" void *symd_create(int max_samples) {
   h->dev = g_device >= 0 ? g_device : 0;
   h->cap = max_samples > 0 ? max_samples : 1;
   CHK(hipSetDevice(h->dev));
-  CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  CHK(dsp_stream_create(&h->st));
   CHK(hipMalloc(&h->d_s, sizeof(int16_t) * ((size_t)h->cap + 8)));
   CHK(hipMemsetAsync(h->d_s, 0, sizeof(int16_t) * ((size_t)h->cap + 8), h->st));     // the reference's buffer comes from calloc-like use: see store ops
   CHK(hipMalloc(&h->d_P, sizeof(long long) * ((size_t)h->cap + 1)));
@@ -932,7 +953,7 @@ extern "C" void *pmd_create(int fftsize) {
   h->dev = g_device >= 0 ? g_device : 0;
   h->N = fftsize; h->logN = lg;
   CHK(hipSetDevice(h->dev));
-  CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  CHK(dsp_stream_create(&h->st));
   CHK(hipMalloc(&h->spec, sizeof(double2) * (size_t)fftsize));
   CHK(hipMalloc(&h->tmp, sizeof(double2) * (size_t)fftsize));
   CHK(hipMalloc(&h->d_iq, sizeof(int16_t) * 2 * (size_t)fftsize));
@@ -1154,7 +1175,7 @@ extern "C" void *isync_create(int corr_size) {
   h->dev = g_device >= 0 ? g_device : 0;
   h->N = corr_size; h->logN = lg;
   CHK(hipSetDevice(h->dev));
-  CHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  CHK(dsp_stream_create(&h->st));
   if (fft_tables(&h->c, corr_size, &h->twA, &h->twB, &h->twR, h->st) != 0) { snprintf(g_err, sizeof g_err, "isync_create: twiddle tables"); goto fail; }
   CHK(hipMalloc(&h->V, sizeof(double2) * (size_t)corr_size));
   CHK(hipMalloc(&h->D, sizeof(double2) * (size_t)corr_size));

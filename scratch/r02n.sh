@@ -1,0 +1,9 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; cd $R
+OUT=gpurun_out/r02n; rm -rf $OUT; mkdir -p $OUT
+for q in 8 4 2 16; do
+export GPU_MAX_HW_QUEUES=$q
+timeout -k 10 300 python3 bench.py --symbols 4000000 --steps 2 --warmup 1 --no-cpu --chain-steps 4 > $OUT/b.json 2> $OUT/b.err || { tail -20 $OUT/b.err; exit 1; }
+python3 -c "import json;d=json.load(open('$OUT/b.json'));print('queues $q: default bench', d['value'], d['config']['split']['single_decoder']['value'], d['config']['split']['single_decoder']['split_avg_launch_ms']); c=d['chain']; print('   chain', c['value'], c['ms_per_step'], c['host_capture']['value'], {k:v for k,v in c['stage_engine_ms'].items() if k!='what'})"
+done
