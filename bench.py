@@ -32,9 +32,6 @@ import time
 
 import numpy as np
 
-# read by the HIP runtime when it initialises (torch does that first here): see csrc/v224_hip.hip, isee3_more_hw_queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 ALG_BYTES_PER_STEP = (1 << 23) * 2 * 2 + (1 << 23) // 8          # read + write u16 metrics + decisions
 HBM_PEAK_GBS = 8000.0
@@ -327,13 +324,14 @@ def main():
     nseg = world * a.segments_per_gpu
     mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
     eng = a.engine if a.engine >= 0 else int(os.environ.get("V224HIP_ENGINE", "3"))
-    chunk = a.chunk or (1024 if eng == 2 else 1020)           # 1020 = 68 x 15 = 204 x 5
+    own_tb = os.environ.get("V224HIP_TB_STREAM", "0") not in ("", "0")
+    chunk = a.chunk or (1024 if eng == 2 else (1020 if own_tb else 2040))           # 1020 = 68 x 15 = 204 x 5
     segs = []
     for g in mine:
         syms, bits, noise_mask = synth.coded_stream(1000 + g, nbits, 3.0, 24.0, 1.0)
         decs = []
         for _ in range(max(1, a.split)):
-            dec = pkg.Viterbi224(a.delay + 2 * chunk, a.engine, a.k)
+            dec = pkg.Viterbi224(a.delay + (2 if own_tb or eng == 2 else 1) * chunk, a.engine, a.k)
             dec.set_option("chunk", chunk)
             decs.append(dec)
         segs.append(dict(dec=decs[0], decs=decs, d_syms=pkg.DeviceBuffer.from_numpy(syms), d_out=pkg.DeviceBuffer(nbits),

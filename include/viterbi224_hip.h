@@ -39,7 +39,7 @@ int v224hip_update_dev(void *p, const uint8_t *d_syms, int nbits);
 
 /* Streaming block decode == for each of nbits: update(1 bit); out[i] = decodebit(delay, 0).
  * out[i] is 0/1, or 0xff while fewer than `delay` steps have run since init (vdecode.c:151-158
- * suppresses exactly those).  Needs len >= delay + 2*v224hip_stream_chunk(p).
+ * suppresses exactly those).  Needs len >= delay + v224hip_stream_chunk(p) (twice the chunk with V224HIP_TB_STREAM=1).
  * `syms`/`out` are host buffers in the first form, device buffers in the _dev form. */
 int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, uint8_t *out);
 int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbits, int delay, uint8_t *d_out);

@@ -22,14 +22,6 @@
 extern "C" void pmd_carrier_params(double cstep, uint64_t *u_hi, uint64_t *u_lo, double *logrho);
 #pragma GCC visibility pop
 
-// HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one run their
-// kernels in order.  A decoder has two streams (trellis passes / tracebacks), a stream shared by two decoders needs four
-// that really run side by side, the chain adds its front-end stages: with 4 queues it depends on the process's history
-// whether two of them collide (measured: one stream on two decoders 2.40 instead of 2.55 Msymbols/s, the chain 364
-// instead of 425 Msamples/s).  The variable is read when the HIP runtime initialises, i.e. at the first HIP call of the
-// process: this runs when the library is loaded, and only sets it if the user has not.
-__attribute__((constructor)) static void isee3_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 static thread_local char g_err[512] = "";
 static int g_device = -1;
 extern "C" const char *isee3dsp_last_error(void) { return g_err; }
@@ -57,14 +49,14 @@ extern "C" void isee3dsp_dev_free(void *d) { if (d) (void)hipFree(d); }
 extern "C" int isee3dsp_h2d(void *d, const void *h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int isee3dsp_d2h(void *h, const void *d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 
-// The front-end kernels are short and their results are waited for by the host; the Viterbi decoder of the same process
-// enqueues hundreds of 18 us launches ahead.  HIP maps streams onto a handful of hardware queues round robin, and a DSP
-// stream that lands on the decoder's queue waits behind all of them (measured: pmdemod 7 -> 38 ms per capture, depending
-// on how many streams the process had created before).  Streams of the highest priority get queues of their own and
-// are dispatched first.
+// Stream of a front-end handle.  (ISEE3DSP_HIGH_PRIORITY=1 asks for the highest stream priority: the front-end kernels are
+// short and the host waits for their results while the decoder of the same process has hundreds of 18 us launches queued.
+// Off by default: with priority queues in the mix the pairing of streams and hardware queues became unpredictable --
+// see tb_own_stream() in v224_hip.hip for what that costs.)
 static hipError_t dsp_stream_create(hipStream_t *st) {
   int least = 0, greatest = 0;
-  if (!getenv("ISEE3DSP_NORMAL_PRIORITY") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+  const char *e = getenv("ISEE3DSP_HIGH_PRIORITY");
+  if (e && atoi(e) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
       hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
   (void)hipGetLastError();
   return hipStreamCreateWithFlags(st, hipStreamNonBlocking);

@@ -58,7 +58,7 @@ struct EvPair { hipEvent_t a, b; unsigned steps, launches; };
 struct V224 {
   int len, engine, K, dev;
   hipStream_t st;           // ACS stream
-  hipStream_t st2;          // traceback stream (stream_decode overlap)
+  hipStream_t st2;          // traceback stream: == st by default, an own stream with V224HIP_TB_STREAM=1 (tb_own_stream())
   uint16_t *m[2];
   int cur;                  // index of the "old" metric buffer
   uint32_t *rows;           // len x 2^18 dwords
@@ -88,15 +88,20 @@ struct V224 {
   size_t dsyms_off;         // update_viterbi224_blk: next free byte of dsyms (symbols of queued launches stay put)
 };
 
-// HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one run their
-// kernels in order.  A decoder has two streams (trellis passes / tracebacks), a stream shared by two decoders needs four
-// that really run side by side, the chain adds its front-end stages: with 4 queues it depends on the process's history
-// whether two of them collide (measured: one stream on two decoders 2.40 instead of 2.55 Msymbols/s, the chain 364
-// instead of 425 Msamples/s).  The variable is read when the HIP runtime initialises, i.e. at the first HIP call of the
-// process: this runs when the library is loaded, and only sets it if the user has not.
-__attribute__((constructor)) static void isee3_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 static int g_device = -1;
+
+// Where a decoder's tracebacks run.  MI355X feeds its compute queues through FOUR hardware pipes, and HIP's hardware
+// queues land on them round robin in the order they are created.  Two busy queues on one pipe do not run side by side, and a
+// queue that waits for a signal of another queue ON THE SAME PIPE stalls it for ~1 ms per wait (measured,
+// scratch/pipe_scan.py: a decoder whose traceback stream is the 4th queue after its pass stream: 1.66 -> 0.62 Msymbols/s;
+// two decoders with own traceback streams and one foreign queue between them: 2.44 -> 1.67; the chain 35 -> 57 ms --
+// all depending on how many streams the process had created and destroyed before).  A decoder with a pass stream AND a
+// traceback stream needs two pipes, two of them all four, and nobody controls which queue gets which.  So by default a
+// decoder has ONE stream: the tracebacks of a chunk run in it, behind the chunk's passes, with the wave-per-bit
+// kernel k_decodebits_spec (~35 us per chunk of any size; another decoder's passes fill the GPU meanwhile).  Two
+// decoders then need two pipes, the whole chain four (two decoders, pmdemod, symdemod).
+// V224HIP_TB_STREAM=1 gives every decoder its own traceback stream again (tracebacks under the next chunk's passes).
+static bool tb_own_stream(void) { const char *e = getenv("V224HIP_TB_STREAM"); return e && atoi(e) != 0; }
 
 extern "C" int v224hip_device_count(void) {
   int n = 0;
@@ -267,6 +272,43 @@ __global__ __launch_bounds__(64) void k_decodebits(const uint32_t *__restrict__ 
     st = (bit << (V224_K - 2)) | (st >> 1);
   }
   out[j] = (uint8_t)bit;
+}
+
+// The same outputs with one WAVE per output bit and six trellis steps per memory round trip (the speculation of
+// k_chainback_spec below: after j steps only 2^j states are possible, so 63 lanes fetch the decisions of all candidates
+// of the next six steps at once): 34 dependent round trips instead of 200.  This is what lets the tracebacks of a chunk
+// run IN the decoder's own stream (~35 us per chunk, whatever its size) instead of on a second one -- see tb_mode().
+__global__ __launch_bounds__(256) void k_decodebits_spec(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta, int len,
+                                                         int dp_first, unsigned long long steps_first, int n, int delay,
+                                                         unsigned endstate, uint8_t *__restrict__ out) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);                  // four output bits per workgroup
+  if (j >= n) return;                                                 // (whole waves leave: no wave-level op below is split)
+  const unsigned lane = threadIdx.x & 63u;
+  if (steps_first + (unsigned long long)j < (unsigned long long)delay) { if (lane == 0) out[j] = 0xff; return; }
+  const unsigned lvl = 31u - (unsigned)__clz((int)(lane + 1u));
+  const unsigned cand = lane + 1u - (1u << lvl);
+  unsigned st = endstate & V224_SMASK, last = 0;
+  int row = (int)(((long long)dp_first + j) % len), remaining = delay;
+  while (remaining > 0) {
+    const int steps = remaining >= 6 ? 6 : remaining;
+    unsigned d = 0;
+    if (lane < 63u && (int)lvl < steps) {
+      int r = (row - 1 - (int)lvl) % len;
+      if (r < 0) r += len;
+      const unsigned cs = ((cand << (V224_SBITS - lvl)) | (st >> lvl)) & V224_SMASK;
+      d = get_decision(rows, rowmeta, r, cs);
+    }
+    unsigned c = 0;
+    for (int k = 0; k < steps; k++) {
+      last = (unsigned)__builtin_amdgcn_readlane((int)d, (int)((1u << k) - 1u + c));
+      c |= last << k;
+    }
+    st = ((c << (V224_SBITS - steps)) | (st >> steps)) & V224_SMASK;
+    row = (row - steps) % len;
+    if (row < 0) row += len;
+    remaining -= steps;
+  }
+  if (lane == 0) out[j] = (uint8_t)last;
 }
 
 // framed chainback, port.c:86-98 (row = n % len).  One lane; the walk is a dependent chain.
@@ -512,7 +554,9 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   if (v->K < 1) v->K = 1;
   if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;
   v->dev = g_device >= 0 ? g_device : env_int("V224HIP_DEVICE", 0);
-  v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : 1020);   // whole passes per chunk (1020 = 68 x 15)
+  // whole passes per chunk (1020 = 68 x 15).  With the tracebacks in the pass stream a chunk costs ~35 us of traceback
+  // latency whatever its size, and the ring only has to hold delay + ONE chunk: the default doubles at equal memory.
+  v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : (tb_own_stream() ? 1020 : 2040));
   HIPCHK(hipSetDevice(v->dev));
   if (v->engine == V224HIP_ENGINE_LDS15) {       // 133 KiB of dynamic LDS per workgroup: above the default cap
     static bool tab_done[64] = {false};
@@ -529,7 +573,13 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
   }
   HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
+  if (tb_own_stream()) {
+    if (getenv("V224HIP_TEST_GAP")) {      // experiment (scratch/pipe_scan.py): GAP other hardware queues created in between
+      static hipStream_t dummies[64]; static int nd = 0;
+      for (int g = 0; g < atoi(getenv("V224HIP_TEST_GAP")) && nd < 64; g++) HIPCHK(hipStreamCreateWithFlags(&dummies[nd++], hipStreamNonBlocking));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
+  } else v->st2 = v->st;                   // tracebacks in the pass stream
   HIPCHK(hipMalloc(&v->m[0], sizeof(uint16_t) * V224_NSTATES));
   HIPCHK(hipMalloc(&v->m[1], sizeof(uint16_t) * V224_NSTATES));
   HIPCHK(hipMalloc(&v->rows, (size_t)len * V224_ROWWORDS * sizeof(uint32_t)));
@@ -545,6 +595,9 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
     HIPCHK(hipEventCreateWithFlags(&v->ev_tb[i], hipEventDisableTiming));
   }
   if (v->engine == V224HIP_ENGINE_LDS15 && len >= 15 && env_int("V224HIP_PLACE", 1) && place_metrics(v) != 0) goto fail;
+  if (getenv("V224HIP_VERBOSE"))
+    fprintf(stderr, "v224hip: create len %d: m0 %p m1 %p rows %p rowmeta %p ds %p dmisc %p\n", len, (void *)v->m[0], (void *)v->m[1],
+            (void *)v->rows, (void *)v->rowmeta, (void *)v->ds, (void *)v->dmisc);
   if (init_viterbi224(v, 0) != 0) goto fail;
   return v;
 fail:
@@ -559,7 +612,7 @@ extern "C" void delete_viterbi224(void *p) {
   if (!v) return;
   (void)hipSetDevice(v->dev);
   if (v->st) (void)hipStreamSynchronize(v->st);
-  if (v->st2) (void)hipStreamSynchronize(v->st2);
+  if (v->st2 && v->st2 != v->st) (void)hipStreamSynchronize(v->st2);
   for (auto &e : v->ev_busy) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : v->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (int i = 0; i < 2; i++) {
@@ -570,14 +623,14 @@ extern "C" void delete_viterbi224(void *p) {
   (void)hipFree(v->ds); (void)hipFree(v->dsyms); (void)hipFree(v->dout); (void)hipFree(v->dmisc);
   (void)hipFree(v->snap[0]); (void)hipFree(v->snap[1]); (void)hipFree(v->warmout);
   for (int i = 0; i < 2; i++) if (v->ev_snap[i]) (void)hipEventDestroy(v->ev_snap[i]);
+  if (v->st2 && v->st2 != v->st) (void)hipStreamDestroy(v->st2);
   if (v->st) (void)hipStreamDestroy(v->st);
-  if (v->st2) (void)hipStreamDestroy(v->st2);
   delete v;
 }
 
 static int init_enqueue(V224 *v, int starting_state, bool wait_tracebacks) {
   HIPCHK(hipSetDevice(v->dev));
-  if (wait_tracebacks) HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
+  if (wait_tracebacks && v->st2 != v->st) HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
   v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0; v->min_valid = true;
   v->layout = 0; v->fresh = true; v->start = (unsigned)starting_state & V224_SMASK;
   k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
@@ -870,11 +923,11 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
     //    switch of the metric order;
     //  * frames of one decoder alternate between the two halves of its ring, and a frame's traceback runs on the
     //    decoder's second stream under the next frame's passes.
-    bool dual = true;
+    bool dual = v0->st2 != v0->st;        // ring halves only pay with an own traceback stream
     const int padbits = v0->engine == V224HIP_ENGINE_LDS15 ? (framebits + 14) / 15 * 15 : framebits;
     for (int i = 0; i < ndec; i++) {
       V224 *v = (V224 *)decoders[i];
-      if (v->len < 2 * padbits || v->engine != v0->engine) dual = false;
+      if (v->len < 2 * padbits || v->engine != v0->engine || v->st2 == v->st) dual = false;
     }
     const int runbits = dual ? padbits : framebits;
     const size_t stride = 2 * (size_t)runbits;
@@ -961,12 +1014,25 @@ extern "C" int v224hip_stream_decode_dev(void *p, const uint8_t *d_syms, int nbi
   V224 *v = (V224 *)p;
   if (!v) return -1;
   if (nbits <= 0) return 0;
-  if (delay <= 0 || v->len < delay + 2 * v->chunk) {
-    snprintf(g_err, sizeof g_err, "stream_decode: need len >= delay + 2*chunk (len=%d delay=%d chunk=%d)",
-             v->len, delay, v->chunk);
+  if (delay <= 0 || v->len < delay + (v->st2 == v->st ? 1 : 2) * v->chunk) {
+    snprintf(g_err, sizeof g_err, "stream_decode: need len >= delay + %d*chunk (len=%d delay=%d chunk=%d)",
+             v->st2 == v->st ? 1 : 2, v->len, delay, v->chunk);
     return -1;
   }
   HIPCHK(hipSetDevice(v->dev));
+  if (v->st2 == v->st) {
+    // one stream: the chunk's passes, then its tracebacks (wave per bit), then the next chunk
+    for (int done = 0; done < nbits;) {
+      int n = nbits - done < v->chunk ? nbits - done : v->chunk;
+      int dp_first = (v->dp + 1) % v->len;            // ring index after the chunk's first step
+      unsigned long long steps_first = v->nsteps + 1;
+      if (enqueue_acs(v, d_syms + 2 * (size_t)done, n) != 0) return -1;
+      k_decodebits_spec<<<(n + 3) / 4, 256, 0, v->st>>>(v->rows, v->rowmeta, v->len, dp_first, steps_first, n, delay, 0u, d_out + done);
+      done += n;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   {
     int c = 0;
     for (int done = 0; done < nbits; c++) {
@@ -1028,7 +1094,7 @@ static int split_core(void *const *decoders, int ndec, const uint8_t *d_syms, in
   V224 *v0 = (V224 *)decoders[0];
   for (int j = 0; j < ndec; j++) {
     V224 *v = (V224 *)decoders[j];
-    if (!v || v->dev != v0->dev || v->chunk != v0->chunk || v->len < delay + 2 * v->chunk) {
+    if (!v || v->dev != v0->dev || v->chunk != v0->chunk || v->len < delay + (v->st2 == v->st ? 1 : 2) * v->chunk) {
       snprintf(g_err, sizeof g_err, "stream_decode_split: decoder %d is NULL, on another device, has another chunk size or a short ring", j);
       return -1;
     }
@@ -1216,7 +1282,7 @@ extern "C" int v224hip_sync(void *p) {
   if (!v) return -1;
   if (hipSetDevice(v->dev) != hipSuccess) return -1;
   if (hipStreamSynchronize(v->st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(v->st2) != hipSuccess) return -1;
+  if (v->st2 != v->st && hipStreamSynchronize(v->st2) != hipSuccess) return -1;
   return 0;
 }
 
