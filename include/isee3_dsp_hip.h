@@ -21,6 +21,9 @@ extern "C" {
 
 const char *isee3dsp_last_error(void);
 int isee3dsp_set_device(int dev);
+/* Handles created by the calling thread while this is on share ONE stream per device instead of getting one each (the
+ * in-process chain turns it on: pmdemod + symdemod + two Viterbi decoders must fit the GPU's four compute pipes). */
+void isee3dsp_share_stream(int on);
 
 /* device / pinned host memory for C callers that keep streams resident in HBM (used by libisee3chain.so) */
 void *isee3dsp_dev_alloc(size_t bytes);

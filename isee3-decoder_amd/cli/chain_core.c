@@ -51,6 +51,7 @@ typedef struct { void *h; int n; } dsp_ctx;       /* remembers the size the hand
 static void *pm_create(int n) {
   dsp_ctx *c = malloc(sizeof *c);
   if (!c) return NULL;
+  isee3dsp_share_stream(1);                          /* one front-end stream for pmdemod and symdemod (isee3_dsp_hip.h: why) */
   c->n = n; c->h = pool_take(g_pm_pool, n);
   if (c->h) pmd_set_dechirp(c->h, NULL);            /* a kept handle may carry the last call's de-chirp table */
   else c->h = pmd_create(n);
@@ -96,6 +97,7 @@ static void pm_destroy(void *p) {
 static void *sy_create(int n) {
   dsp_ctx *c = malloc(sizeof *c);
   if (!c) return NULL;
+  isee3dsp_share_stream(1);
   c->n = n; c->h = pool_take(g_sy_pool, n);
   if (c->h) symd_store_reset(c->h);                 /* a kept handle: its window buffer starts out zero again */
   else c->h = symd_create(n);

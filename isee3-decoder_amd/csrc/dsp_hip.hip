@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 #pragma GCC visibility push(default)
 #include "../../include/isee3_dsp_hip.h"
@@ -49,11 +50,26 @@ extern "C" void isee3dsp_dev_free(void *d) { if (d) (void)hipFree(d); }
 extern "C" int isee3dsp_h2d(void *d, const void *h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int isee3dsp_d2h(void *h, const void *d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 
-// Stream of a front-end handle.  (ISEE3DSP_HIGH_PRIORITY=1 asks for the highest stream priority: the front-end kernels are
-// short and the host waits for their results while the decoder of the same process has hundreds of 18 us launches queued.
-// Off by default: with priority queues in the mix the pairing of streams and hardware queues became unpredictable --
-// see tb_own_stream() in v224_hip.hip for what that costs.)
-static hipError_t dsp_stream_create(hipStream_t *st) {
+// Stream of a front-end handle: its own, or -- for handles created while isee3dsp_share_stream(1) is in force in the
+// creating thread -- ONE stream per device shared by all such handles (never destroyed).  Why share: MI355X feeds compute
+// queues through four hardware pipes; HIP's hardware queues land on them in creation order (queue 0 = the null stream),
+// and only queues 1..3 run side by side with each other without one starving the other (v224_hip.hip, tb_own_stream).  The
+// in-process chain needs two Viterbi decoders and the front end at the same time: with pmdemod and symdemod on one
+// stream that is three.  Their kernels are short and the two stages' host threads synchronise on results anyway.
+// (ISEE3DSP_HIGH_PRIORITY=1 asks for the highest stream priority for own streams; off by default: with priority queues
+// in the mix the pairing of streams and hardware queues became even less predictable.)
+static thread_local int t_share_stream = 0;
+static hipStream_t g_shared_stream[64];
+extern "C" void isee3dsp_share_stream(int on) { t_share_stream = on; }
+static hipError_t dsp_stream_create(hipStream_t *st, int *owned) {
+  int dev = 0;
+  *owned = 1;
+  if (t_share_stream && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!g_shared_stream[dev] && hipStreamCreateWithFlags(&g_shared_stream[dev], hipStreamNonBlocking) != hipSuccess) g_shared_stream[dev] = nullptr;
+    if (g_shared_stream[dev]) { *st = g_shared_stream[dev]; *owned = 0; return hipSuccess; }
+  }
   int least = 0, greatest = 0;
   const char *e = getenv("ISEE3DSP_HIGH_PRIORITY");
   if (e && atoi(e) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
@@ -94,7 +110,7 @@ static void pin_free(Pin *p) { if (p->h) (void)hipHostFree(p->h); p->h = p->d = 
 #define SCAN_ROW 264                         // LDS row stride (8-byte words) of the transposed prefix image
 
 struct Symd {
-  int dev; hipStream_t st;
+  int dev; hipStream_t st; int own_st;
   int cap, n;
   int16_t *d_s, *d_s2;                       // the window buffer and its ping-pong partner (store_slide)
   long long *d_P; long long *d_blk; int nblk_cap;
@@ -355,7 +371,7 @@ extern "C" void *symd_create(int max_samples) {
   h->dev = g_device >= 0 ? g_device : 0;
   h->cap = max_samples > 0 ? max_samples : 1;
   CHK(hipSetDevice(h->dev));
-  CHK(dsp_stream_create(&h->st));
+  CHK(dsp_stream_create(&h->st, &h->own_st));
   CHK(hipMalloc(&h->d_s, sizeof(int16_t) * ((size_t)h->cap + 8)));
   CHK(hipMemsetAsync(h->d_s, 0, sizeof(int16_t) * ((size_t)h->cap + 8), h->st));     // the reference's buffer comes from calloc-like use: see store ops
   CHK(hipMalloc(&h->d_P, sizeof(long long) * ((size_t)h->cap + 1)));
@@ -371,7 +387,7 @@ extern "C" void symd_destroy(void *p) {
   Symd *h = (Symd *)p;
   if (!h) return;
   (void)hipSetDevice(h->dev);
-  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  if (h->st) { (void)hipStreamSynchronize(h->st); if (h->own_st) (void)hipStreamDestroy(h->st); }
   (void)hipFree(h->d_s); (void)hipFree(h->d_s2); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
   (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym); (void)hipFree(h->d_part); (void)hipFree(h->d_terms);
   (void)hipFree(h->d_flag);
@@ -535,7 +551,7 @@ fail:
 // pmdemod
 // ===========================================================================================
 struct Pmd {
-  int dev; hipStream_t st;
+  int dev; hipStream_t st; int own_st;
   int N, logN;
   double2 *buf, *spec, *tmp, *tw, *lo;   // buf / tw: only for N < 2^12 (register-radix path); lo = optional de-chirp table
   double2 *twA, *twB, *twR;              // LDS-pass path: W_N^(4096 h), W_N^l (l < 4096), W_256^m
@@ -945,7 +961,7 @@ extern "C" void *pmd_create(int fftsize) {
   h->dev = g_device >= 0 ? g_device : 0;
   h->N = fftsize; h->logN = lg;
   CHK(hipSetDevice(h->dev));
-  CHK(dsp_stream_create(&h->st));
+  CHK(dsp_stream_create(&h->st, &h->own_st));
   CHK(hipMalloc(&h->spec, sizeof(double2) * (size_t)fftsize));
   CHK(hipMalloc(&h->tmp, sizeof(double2) * (size_t)fftsize));
   CHK(hipMalloc(&h->d_iq, sizeof(int16_t) * 2 * (size_t)fftsize));
@@ -973,7 +989,7 @@ extern "C" void pmd_destroy(void *p) {
   Pmd *h = (Pmd *)p;
   if (!h) return;
   (void)hipSetDevice(h->dev);
-  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  if (h->st) { (void)hipStreamSynchronize(h->st); if (h->own_st) (void)hipStreamDestroy(h->st); }
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red);
@@ -1105,7 +1121,7 @@ fail:
 // vector, conjugated: icesync.c:122-135), the zero-padded frame's (:151-163), and the inverse of their product (:166-170;
 // FFTW's unnormalised c2r = Re(FFT(conj(Y)))).  Then the first maximum > 0 in [low, high), folded above size/2 (:188-206).
 struct Isync {
-  int dev; hipStream_t st;
+  int dev; hipStream_t st; int own_st;
   int N, logN; FftCtx c;
   double2 *twA, *twB, *twR;
   double2 *V, *D, *R, *tmp;        // conj(FFT(vec)), FFT(frame), result, ping-pong
@@ -1167,7 +1183,7 @@ extern "C" void *isync_create(int corr_size) {
   h->dev = g_device >= 0 ? g_device : 0;
   h->N = corr_size; h->logN = lg;
   CHK(hipSetDevice(h->dev));
-  CHK(dsp_stream_create(&h->st));
+  CHK(dsp_stream_create(&h->st, &h->own_st));
   if (fft_tables(&h->c, corr_size, &h->twA, &h->twB, &h->twR, h->st) != 0) { snprintf(g_err, sizeof g_err, "isync_create: twiddle tables"); goto fail; }
   CHK(hipMalloc(&h->V, sizeof(double2) * (size_t)corr_size));
   CHK(hipMalloc(&h->D, sizeof(double2) * (size_t)corr_size));
@@ -1185,7 +1201,7 @@ extern "C" void isync_destroy(void *p) {
   Isync *h = (Isync *)p;
   if (!h) return;
   (void)hipSetDevice(h->dev);
-  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  if (h->st) { (void)hipStreamSynchronize(h->st); if (h->own_st) (void)hipStreamDestroy(h->st); }
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->V); (void)hipFree(h->D); (void)hipFree(h->R); (void)hipFree(h->tmp); (void)hipFree(h->d_s); (void)hipFree(h->d_red);
   free(h);
