@@ -194,6 +194,36 @@ def chain_record(a, ctx, seconds, rate, binsize, steps, warmup, with_cpu):
     return rec
 
 
+def frames_record(pkg, synth, nframes=50, framebits=1000):
+    """configs[0]'s shape -- vtest224's init / update(framebits) / chainback per frame (vtest224.c:116-118, 170-176), 50 frames
+    of 1 000 bits -- as one v224hip_decode_frames batch on two and on three decoder objects (what `decode -V` uses)."""
+    frames, sent = [], []
+    for f in range(nframes):
+        syms, bits, _ = synth.coded_stream(5000 + f, framebits, 3.0, 24.0, 0.0)
+        frames.append(syms[:2 * framebits]); sent.append(bits[:framebits])
+    syms = np.concatenate(frames)
+    rows = 2 * ((framebits + 14) // 15 * 15)
+    decs = [pkg.Viterbi224(rows) for _ in range(3)]
+    rec = {"what": "%d independent frames of %d bits (BASELINE configs[0] shape), v224hip_decode_frames, host buffers in and "
+                   "out (H2D of the symbols and D2H of the bytes inside the time)" % (nframes, framebits)}
+    out = None
+    for nd in (2, 3):
+        pkg.decode_frames(decs[:nd], syms, min(nframes, 8), framebits)
+        t0 = time.perf_counter()
+        got = pkg.decode_frames(decs[:nd], syms, nframes, framebits)
+        dt = time.perf_counter() - t0
+        rec["decoders_%d" % nd] = {"ms_per_frame": round(dt * 1e3 / nframes, 4), "Msymbols_per_s": round(2 * framebits * nframes / dt / 1e6, 4)}
+        rec["identical_output"] = bool(out is None or np.array_equal(out, got)) and rec.get("identical_output", True)
+        out = got
+    # decoded data = sent data away from the unterminated frame end (the oracle comparison lives in tests/)
+    dec, ref = np.unpackbits(out, axis=1)[:, :framebits], np.stack(sent)
+    n = framebits - 150                                  # (the frames are not terminated: the last bits hang on the end state)
+    rec["ber_away_from_frame_end"] = min(float(np.mean(dec[:, sh:sh + n] != ref[:, :n])) for sh in range(0, 25))
+    for d in decs:
+        d.close()
+    return rec
+
+
 def chain_workload(a, ctx):
     """`--workload chain`: the chain line alone (profiling), or -- with --chain-segments S > 1 -- BASELINE configs[4]:
     ONE capture cut into S overlapped block-aligned segments, segment g -> rank g mod world, two chains at a time per
@@ -273,6 +303,7 @@ def main():
     ap.add_argument("--split-warm", type=int, default=14280, help="warm-up bits before each part (14 chunks)")
     ap.add_argument("--cpu-bits", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-frames", action="store_true", help="skip the framed-batch record")
     ap.add_argument("--no-chain", action="store_true", help="skip the chain half of the metric (kernel profiling runs)")
     ap.add_argument("--workload", choices=["viterbi", "chain"], default="viterbi")
     ap.add_argument("--chain-seconds", type=float, default=60.0)
@@ -406,6 +437,7 @@ def main():
             d.close()
         sg["d_syms"].free(); sg["d_out"].free()
 
+    frames = frames_record(pkg, synth) if not a.no_frames and eng == 3 else None
     chain = None
     if not a.no_chain:
         chain = chain_record(a, ctx, a.chain_seconds, a.chain_rate, a.chain_bin, a.chain_steps or a.steps, max(1, a.warmup),
@@ -477,6 +509,8 @@ def main():
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(a.cpu_bits)
             res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+        if frames is not None:
+            res["frames"] = frames
         if chain is not None:
             res["chain"] = chain
         print(json.dumps(res), flush=True)

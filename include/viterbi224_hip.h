@@ -79,6 +79,11 @@ int v224hip_decode_frames(void *const *decoders, int ndec, const uint8_t *syms, 
  * stream).  -1 on unknown key / bad value. */
 int v224hip_set_option(void *p, const char *key, long value);
 
+/* Counters, read and reset.  "chainback_redone": chainback_viterbi224 / v224hip_decode_frames walk a frame of 512 ..
+ * 81 920 bits in 16 pieces at once, each piece checked against the one above it; this counts the pieces that failed the
+ * check and were walked again from the true state (the output is the serial walk's either way).  -1 on unknown key. */
+long v224hip_get_counter(void *p, const char *key);
+
 /* Block until all enqueued work of this decoder has finished. */
 int v224hip_sync(void *p);
 

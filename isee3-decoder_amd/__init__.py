@@ -30,7 +30,7 @@ V224_SYMBOLS = [
     "decodebit_viterbi224", "decodeword_viterbi224",
     "v224hip_device_count", "v224hip_set_device", "v224hip_create", "v224hip_last_error",
     "v224hip_update_dev", "v224hip_stream_decode", "v224hip_stream_decode_dev",
-    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_stream_decode_shared", "v224hip_set_option", "v224hip_sync", "v224hip_acs_stats",
+    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_stream_decode_shared", "v224hip_set_option", "v224hip_get_counter", "v224hip_sync", "v224hip_acs_stats",
     "v224hip_export_row", "v224hip_export_metrics", "v224hip_dev_alloc", "v224hip_dev_free",
     "v224hip_h2d", "v224hip_d2h",
 ]
@@ -85,6 +85,8 @@ def v224_lib():
                                         C.c_uint, u8p]
     L.v224hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     L.v224hip_sync.argtypes = [C.c_void_p]
+    L.v224hip_get_counter.argtypes = [C.c_void_p, C.c_char_p]
+    L.v224hip_get_counter.restype = C.c_long
     L.v224hip_acs_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double),
                                     C.POINTER(C.c_ulonglong), C.c_int]
     L.v224hip_export_row.argtypes = [C.c_void_p, C.c_int, u8p]
@@ -213,6 +215,13 @@ class Viterbi224:
 
     def stream_chunk(self):
         return self.L.v224hip_stream_chunk(self.h)
+
+    def get_counter(self, key):
+        """Read and reset a counter ("chainback_redone": pieces of parallel chainbacks walked again after a failed seam check)."""
+        r = self.L.v224hip_get_counter(self.h, key.encode())
+        if r < 0:
+            raise RuntimeError("v224hip_get_counter %s failed: %s" % (key, last_error()))
+        return int(r)
 
     def sync(self):
         return self._chk(self.L.v224hip_sync(self.h), "v224hip_sync")

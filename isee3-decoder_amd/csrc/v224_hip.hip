@@ -358,6 +358,85 @@ __global__ __launch_bounds__(64) void k_chainback_spec(const uint32_t *__restric
   }
 }
 
+// Framed chainback in 16 pieces at once (one workgroup of 16 waves), results identical to the serial walk by
+// construction.  Wave w owns the steps of output bytes [w*nbytes/16, (w+1)*nbytes/16).  The top wave starts from the
+// caller's end state; every other wave starts CB_WARM steps above its piece from state 0: survivor paths merge going
+// back in time (after a few constraint lengths on a decodable frame), so by the time it reaches its piece it is
+// normally on the true path.  "Normally" is then checked: going down from the top, the state a piece was entered with
+// must equal the state the piece above (already known to be true) left with; a piece that fails is walked again from
+// the true state by wave 0 before the check goes on.  So a frame of merged paths costs (piece + warm-up)/6 memory
+// round trips instead of nbits/6 (1 024 bits: 43 instead of 171), and a frame of pure noise at worst ~1.3x the serial walk.
+#define CB_WAVES 16
+#define CB_WARM 192
+#define CB_MAXBYTES 10240                     /* 81 920 bits: vtest224.c:30 caps frames at 80 000 */
+#define CB_MINBITS 512
+
+// steps n_from .. n_to (downwards, inclusive) of the port's loop from state st; bytes go to obuf (LDS) unless null
+__device__ __forceinline__ unsigned cb_walk(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta, int len,
+                                            unsigned row0, long long n_from, long long n_to, unsigned st, uint8_t *obuf,
+                                            unsigned lane, unsigned lvl, unsigned cand) {
+  unsigned acc = 0;
+  long long n = n_from;
+  while (n >= n_to) {
+    const int steps = n - n_to >= 5 ? 6 : (int)(n - n_to + 1);
+    unsigned d = 0;
+    if (lane < 63u && (int)lvl < steps) {
+      const unsigned cs = ((cand << (V224_SBITS - lvl)) | (st >> lvl)) & V224_SMASK;
+      d = get_decision(rows, rowmeta, (int)((unsigned long long)(row0 + n - lvl) % (unsigned)len), cs);
+    }
+    unsigned c = 0;
+    for (int j = 0; j < steps; j++) {
+      const unsigned nn = (unsigned)(n - j);
+      acc = (((st >> j) & 1u) << 7) | (acc >> 1);
+      if (obuf && (nn & 7u) == 0 && lane == 0) obuf[nn >> 3] = (uint8_t)acc;
+      const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)d, (int)((1u << j) - 1u + c));
+      c |= b << j;
+    }
+    st = ((c << (V224_SBITS - steps)) | (st >> steps)) & V224_SMASK;
+    n -= steps;
+  }
+  return st;
+}
+
+__global__ __launch_bounds__(CB_WAVES * 64) void k_chainback_par(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta,
+                                                                 int len, unsigned nbits, unsigned endstate,
+                                                                 uint8_t *__restrict__ data, unsigned row0, unsigned *__restrict__ redone) {
+  __shared__ unsigned s_in[CB_WAVES], s_out[CB_WAVES];
+  __shared__ uint8_t s_data[CB_MAXBYTES];
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const unsigned lvl = 31u - (unsigned)__clz((int)(lane + 1u));
+  const unsigned cand = lane + 1u - (1u << lvl);
+  const unsigned nbytes = (nbits + 7u) >> 3;
+  auto piece_lo = [&](unsigned k) { return (long long)(8u * (k * nbytes / CB_WAVES)); };          // first step of piece k
+  auto piece_hi = [&](unsigned k) { return k + 1 == CB_WAVES ? (long long)nbits : piece_lo(k + 1); };   // one past its last
+  {
+    const long long lo = piece_lo(w), hi = piece_hi(w);
+    long long top = hi + CB_WARM;
+    unsigned st = 0;
+    if (top >= (long long)nbits) { top = nbits; st = endstate & V224_SMASK; }                    // nothing to guess
+    if (top > hi) st = cb_walk(rows, rowmeta, len, row0, top - 1, hi, st, nullptr, lane, lvl, cand);
+    if (lane == 0) s_in[w] = st;
+    st = cb_walk(rows, rowmeta, len, row0, hi - 1, lo, st, s_data, lane, lvl, cand);
+    if (lane == 0) s_out[w] = st;
+  }
+  __syncthreads();
+  unsigned cur = s_out[CB_WAVES - 1], nredo = 0;             // the top piece started from the caller's end state: true
+  for (int k = CB_WAVES - 2; k >= 0; k--) {
+    if (s_in[k] != cur) {                                    // (same value in every thread: the barriers below are uniform)
+      if (w == 0) {
+        const unsigned st = cb_walk(rows, rowmeta, len, row0, piece_hi(k) - 1, piece_lo(k), cur, s_data, lane, lvl, cand);
+        if (lane == 0) s_out[k] = st;
+      }
+      nredo++;
+      __syncthreads();
+    }
+    cur = s_out[k];
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < nbytes; i += CB_WAVES * 64) data[i] = s_data[i];
+  if (redone && threadIdx.x == 0 && nredo) atomicAdd(redone, nredo);
+}
+
 // decodebit (port.c:124-141) with the same six-steps-per-round-trip speculation: walk `delay` rows back from dp with
 // ring wrap, return the last decision read.  (One call of the reference's per-bit pattern = one of these.)
 __global__ __launch_bounds__(64) void k_decodebit_spec(const uint32_t *__restrict__ rows,
@@ -590,6 +669,7 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   HIPCHK(hipMalloc(&v->ds, sizeof(V224Dev)));
   v->dmisc_cap = 1 << 20;
   HIPCHK(hipMalloc(&v->dmisc, v->dmisc_cap));
+  HIPCHK(hipMemsetAsync(v->dmisc, 0, 4096, v->st));      // (counters live here: chainback pieces redone at +96)
   for (int i = 0; i < 2; i++) {
     HIPCHK(hipEventCreateWithFlags(&v->ev_acs[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&v->ev_tb[i], hipEventDisableTiming));
@@ -874,6 +954,16 @@ fail:
   return 0;
 }
 
+// framed chainback on stream st: 16 verified pieces at once where the frame is long enough, else the serial walk
+static void launch_chainback(V224 *v, hipStream_t st, unsigned nbits, unsigned endstate, uint8_t *d_out, unsigned row0) {
+  static const int serial = getenv("V224HIP_SERIAL_CHAINBACK") ? atoi(getenv("V224HIP_SERIAL_CHAINBACK")) : 0;   // 1: one lane, 2: one wave
+  if (serial == 1 && row0 == 0) k_chainback<<<1, 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out);
+  else if (serial || nbits < CB_MINBITS || nbits > 8u * CB_MAXBYTES)
+    k_chainback_spec<<<1, 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out, row0);
+  else
+    k_chainback_par<<<1, CB_WAVES * 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out, row0, (unsigned *)(v->dmisc + 96));
+}
+
 extern "C" int chainback_viterbi224(void *p, unsigned char *data, unsigned int nbits,
                                     unsigned int endstate) {
   V224 *v = (V224 *)p;
@@ -883,8 +973,7 @@ extern "C" int chainback_viterbi224(void *p, unsigned char *data, unsigned int n
     size_t nbytes = (nbits + 7) / 8;
     HIPCHK(hipSetDevice(v->dev));
     if (ensure_cap(&v->dout, &v->dout_cap, nbytes) != 0) return -1;
-    if (getenv("V224HIP_SERIAL_CHAINBACK")) k_chainback<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, v->dout);
-    else k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, v->dout);
+    launch_chainback(v, v->st, nbits, endstate, v->dout, 0);
     // the port writes data[n>>3] only where (n & 7) == 0, i.e. nbits/8 bytes (+1 if ragged)
     HIPCHK(hipMemcpyAsync(data, v->dout, nbytes, hipMemcpyDeviceToHost, v->st));
     HIPCHK(hipStreamSynchronize(v->st));
@@ -953,11 +1042,10 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
       if (dual) {
         HIPCHK(hipEventRecord(v->ev_acs[h], v->st));
         HIPCHK(hipStreamWaitEvent(v->st2, v->ev_acs[h], 0));
-        k_chainback_spec<<<1, 64, 0, v->st2>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f,
-                                              (unsigned)(h * padbits));
+        launch_chainback(v, v->st2, (unsigned)framebits, endstate, d_out + outbytes * f, (unsigned)(h * padbits));
         HIPCHK(hipEventRecord(v->ev_tb[h], v->st2));
       } else
-        k_chainback_spec<<<1, 64, 0, v->st>>>(v->rows, v->rowmeta, v->len, (unsigned)framebits, endstate, d_out + outbytes * f);
+        launch_chainback(v, v->st, (unsigned)framebits, endstate, d_out + outbytes * f, 0);
     }
     HIPCHK(hipGetLastError());
     for (int i = 0; i < ndec; i++) {
@@ -1274,6 +1362,21 @@ extern "C" int v224hip_set_option(void *p, const char *key, long value) {
   if (!v || !key) return -1;
   if (!strcmp(key, "chunk")) { if (value < 1) return -1; v->chunk = (int)value; return 0; }
   if (!strcmp(key, "profile")) { if (value < 0) return -1; v->profile = (int)value; return 0; }
+  return -1;
+}
+
+// "chainback_redone": pieces of parallel framed chainbacks that failed their seam check and were walked again (read and reset)
+extern "C" long v224hip_get_counter(void *p, const char *key) {
+  V224 *v = (V224 *)p;
+  unsigned c = 0;
+  if (!v || !key || strcmp(key, "chainback_redone")) return -1;
+  HIPCHK(hipSetDevice(v->dev));
+  if (v->st2 != v->st) HIPCHK(hipStreamSynchronize(v->st2));
+  HIPCHK(hipMemcpyAsync(&c, v->dmisc + 96, sizeof c, hipMemcpyDeviceToHost, v->st));
+  HIPCHK(hipMemsetAsync(v->dmisc + 96, 0, sizeof c, v->st));
+  HIPCHK(hipStreamSynchronize(v->st));
+  return (long)c;
+fail:
   return -1;
 }
 

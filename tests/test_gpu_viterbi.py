@@ -271,6 +271,38 @@ def test_config1_framed_frames_vs_oracle(pkg, dist):
     o.close()
 
 
+@pytest.mark.parametrize("nbits", [511, 512, 519, 1024, 1031, 3000, 4099])
+def test_chainback_in_pieces_equals_serial_walk(pkg, nbits):
+    """chainback_viterbi224 walks frames of >= 512 bits in 16 pieces at once, each verified against the piece above
+    (k_chainback_par).  Bytes equal the oracle's (port.c:72-101) for bit counts that are not multiples of 8 or 16 bytes, on a
+    coded frame (pieces merge: nothing redone), and on pure noise / all-erasure input (paths do not merge within the
+    warm-up: the seam check must catch it and walk those pieces again), for non-zero end states too."""
+    cases = {
+        "coded": orc.gen_coded_stream(7700 + nbits, nbits, 3.0, 24.0)[0],
+        "noise": orc.gen_uniform(7800 + nbits, 2 * nbits),
+        "erased": np.full(2 * nbits, 128, dtype=np.uint8),
+    }
+    d = pkg.Viterbi224(nbits)
+    o = orc.OracleV224(nbits, orc.FAST)
+    redone = {}
+    for name, syms in cases.items():
+        for dec in (d, o):
+            dec.init(0)
+            dec.update(syms, nbits)
+        d.get_counter("chainback_redone")
+        for end in (0, 0x5a5a5a, 0x7fffff):
+            assert np.array_equal(d.chainback(nbits, end), o.chainback(nbits, end)), "%s end %x" % (name, end)
+        redone[name] = d.get_counter("chainback_redone")
+    if nbits < 512:
+        assert sum(redone.values()) == 0                      # serial walk: the counter never moves
+    else:
+        assert redone["coded"] == 0, redone                   # survivor paths of a decodable frame merge inside the warm-up
+        if nbits >= 1024:
+            assert redone["noise"] + redone["erased"] > 0, redone     # the check is not vacuous
+    d.close()
+    o.close()
+
+
 def test_decode_frames_batch_on_two_decoders(pkg):
     """v224hip_decode_frames: 7 independent 1000-bit frames (vtest224.c:116-118 per frame) spread over two
     decoders on two streams -- every frame's bytes equal to the oracle's, for a non-zero start / end state too."""
