@@ -41,6 +41,17 @@ def test_reference_vtest224_source_on_hip_library():
     assert int(m.group(1)) == 0 and int(m.group(2)) == 3 * 512 and int(m.group(3)) == 0
 
 
+def test_reference_hybridtest_source_on_hip_library():
+    """hybridtest.c (Fano first, create / init / update / chainback / delete per failed frame, hybridtest.c:186-193):
+    with one Fano move per bit every frame falls through to the Viterbi decoder, which at 4.5 dB must return the data."""
+    p = subprocess.run([_exe("hybridtest_hiplink"), "-m", "1", "-n", "4", "-e", "4.5"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    m = re.search(rb"Viterbi attempts (\d+) good frames: (\d+) frame errors (\d+)", p.stdout)
+    assert m, p.stdout
+    assert int(m.group(1)) >= 3 and int(m.group(2)) == int(m.group(1)) and int(m.group(3)) == 0
+
+
 def test_reference_decode_source_on_hip_library():
     """decode.c -V (frame sync, init(sync state) / update(1024) / chainback per frame,
     hex frame dump) unmodified on the HIP library == the same program on viterbi224_port.c."""
