@@ -66,6 +66,21 @@ int v224hip_stream_decode_split(void *const *decoders, int ndec, const uint8_t *
 int v224hip_stream_decode_shared(void *const *decoders, int ndec, int *holder, const uint8_t *syms, int nbits,
                                  int delay, uint8_t *out, int warm_bits);
 
+/* The same for a stream that is still ARRIVING (host buffers), with ONE warm-up for the whole stream.  begin() takes the
+ * expected length; feed() appends the symbols of the next nbits trellis steps and enqueues whatever can run now (it does
+ * not wait for the GPU); decoder 0 decodes from the first symbol on, decoder 1 joins from a fresh init `warm_bits` before
+ * the cut and runs to the end.  The cut is placed when decoder 1 can start: x = (expected + warm + what decoder 0 has
+ * finished by then) / 2, so that both finish together -- the middle when all symbols are there at once, later when they
+ * trickle in, never when one decoder keeps up with them.  end() finishes, verifies the seam as above (decoder 0 decodes
+ * the second part again if the check fails: *redone = 1), writes all bits -- exactly what one decoder's
+ * v224hip_stream_decode() of the whole stream writes -- and releases the handle (also on failure).  A wrong expectation
+ * only misplaces the cut.  Both decoders: same device and chunk, len >= delay + chunk; they are (re-)initialised by these
+ * calls.  NULL / -1 on failure (v224hip_last_error()); abort() drops a handle without finishing. */
+void *v224hip_progressive_begin(void *const *decoders, int ndec, long long expected_bits, int delay, int warm_bits);
+int   v224hip_progressive_feed(void *h, const uint8_t *syms, int nbits);
+int   v224hip_progressive_end(void *h, uint8_t *out, long long cap, long long *nbits_out, int *redone);
+void  v224hip_progressive_abort(void *h);
+
 /* A batch of independent frames, each decoded as vtest224.c:116-118 / decode.c:220-222 do it:
  *   init_viterbi224(d, startstate); update_viterbi224_blk(d, syms + f*2*framebits, framebits);
  *   chainback_viterbi224(d, out + f*((framebits+7)/8), framebits, endstate);

@@ -30,7 +30,7 @@ V224_SYMBOLS = [
     "decodebit_viterbi224", "decodeword_viterbi224",
     "v224hip_device_count", "v224hip_set_device", "v224hip_create", "v224hip_last_error",
     "v224hip_update_dev", "v224hip_stream_decode", "v224hip_stream_decode_dev",
-    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_stream_decode_shared", "v224hip_set_option", "v224hip_get_counter", "v224hip_sync", "v224hip_acs_stats",
+    "v224hip_stream_chunk", "v224hip_decode_frames", "v224hip_stream_decode_split", "v224hip_stream_decode_shared", "v224hip_progressive_begin", "v224hip_progressive_feed", "v224hip_progressive_end", "v224hip_progressive_abort", "v224hip_set_option", "v224hip_get_counter", "v224hip_sync", "v224hip_acs_stats",
     "v224hip_export_row", "v224hip_export_metrics", "v224hip_dev_alloc", "v224hip_dev_free",
     "v224hip_h2d", "v224hip_d2h",
 ]
@@ -83,6 +83,12 @@ def v224_lib():
                                               C.c_int, C.POINTER(C.c_int)]
     L.v224hip_decode_frames.argtypes = [C.POINTER(C.c_void_p), C.c_int, u8p, C.c_int, C.c_int, C.c_int,
                                         C.c_uint, u8p]
+    L.v224hip_progressive_begin.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_longlong, C.c_int, C.c_int]
+    L.v224hip_progressive_begin.restype = C.c_void_p
+    L.v224hip_progressive_feed.argtypes = [C.c_void_p, u8p, C.c_int]
+    L.v224hip_progressive_end.argtypes = [C.c_void_p, u8p, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+    L.v224hip_progressive_abort.argtypes = [C.c_void_p]
+    L.v224hip_progressive_abort.restype = None
     L.v224hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     L.v224hip_sync.argtypes = [C.c_void_p]
     L.v224hip_get_counter.argtypes = [C.c_void_p, C.c_char_p]
@@ -294,6 +300,42 @@ def stream_decode_shared(decoders, holder, syms, delay, warm_bits=4080):
     if rc != 0:
         raise RuntimeError("v224hip_stream_decode_shared: " + L.v224hip_last_error().decode())
     return out, h.value
+
+
+class ProgressiveDecode:
+    """v224hip_progressive_*: a stream that is still arriving, on two decoders with one warm-up, exactly as one decoder
+    would decode it.  feed(symbols) as they come, end() -> (bits uint8[n], redone)."""
+
+    def __init__(self, decoders, expected_bits, delay, warm_bits=3060):
+        self.L = v224_lib()
+        hs = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+        self.h = self.L.v224hip_progressive_begin(hs, len(decoders), int(expected_bits), int(delay), int(warm_bits))
+        if not self.h:
+            raise RuntimeError("v224hip_progressive_begin: " + self.L.v224hip_last_error().decode())
+        self.fed = 0
+
+    def feed(self, syms):
+        syms = np.ascontiguousarray(syms, dtype=np.uint8)
+        n = len(syms) // 2
+        if self.L.v224hip_progressive_feed(self.h, syms.ctypes.data_as(u8p), n) != 0:
+            raise RuntimeError("v224hip_progressive_feed: " + self.L.v224hip_last_error().decode())
+        self.fed += n
+
+    def end(self):
+        out = np.empty(max(self.fed, 1), dtype=np.uint8)
+        n, redone = C.c_longlong(0), C.c_int(0)
+        h, self.h = self.h, None
+        if self.L.v224hip_progressive_end(h, out.ctypes.data_as(u8p), len(out), C.byref(n), C.byref(redone)) != 0:
+            raise RuntimeError("v224hip_progressive_end: " + self.L.v224hip_last_error().decode())
+        return out[:n.value], redone.value
+
+    def abort(self):
+        if self.h:
+            self.L.v224hip_progressive_abort(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.abort()
 
 
 def decode_frames(decoders, syms, nframes, framebits, startstate=0, endstate=0):

@@ -128,8 +128,9 @@ static void chunk_from_env(void) {
 }
 /* vdecode engine: one decoder for block-wise streaming; for one long stream (whole-input mode) a second decoder joins
  * and the stream is decoded in two halves at once, verified at the seam (v224hip_stream_decode_split) */
-typedef struct { void *d[2]; int len, holder; volatile int *front_done; } vd_ctx;   /* holder: the decoder that carries the stream's state */
+typedef struct { void *d[2]; int len, holder; volatile int *front_done; long long expected; void *prog; } vd_ctx;   /* holder: the decoder that carries the stream's state */
 static __thread volatile int *t_front_done;      /* set by the chain for its vdecode thread: 1 once symdemod has finished */
+static __thread long long t_expected_bits;       /* ditto: decoded bits the capture should give (places the cut of the progressive decode) */
 /* Viterbi decoders (2.2 GiB decision ring, placement probe) are kept between calls too: a few, so that concurrent
  * chains each find one. */
 #define VD_POOL 4
@@ -137,12 +138,14 @@ static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static vd_ctx *g_pool[VD_POOL];
 static void vd_free(vd_ctx *c) {
   if (!c) return;
+  if (c->prog) { v224hip_progressive_abort(c->prog); c->prog = NULL; }
   for (int i = 0; i < 2; i++) if (c->d[i]) delete_viterbi224(c->d[i]);
   free(c);
 }
 static void vd_destroy(void *p) {
   vd_ctx *c = p;
   if (!c) return;
+  if (c->prog) { v224hip_progressive_abort(c->prog); c->prog = NULL; }     /* a run that failed half-way */
   pthread_mutex_lock(&g_pool_mu);
   for (int i = 0; i < VD_POOL; i++) if (!g_pool[i]) { g_pool[i] = c; c = NULL; break; }
   pthread_mutex_unlock(&g_pool_mu);
@@ -176,7 +179,11 @@ static void *vd_create(int len) {
   v224hip_set_option(c->d[0], "chunk", g_chunk);
   return c;
 }
-static int vd_init(void *h, int s) { vd_ctx *c = h; c->holder = 0; c->front_done = t_front_done; return init_viterbi224(c->d[0], s); }
+static int vd_init(void *h, int s) {
+  vd_ctx *c = h;
+  c->holder = 0; c->front_done = t_front_done; c->expected = t_expected_bits;
+  return init_viterbi224(c->d[0], s);
+}
 #define VD_SPLIT_WARM (4 * 1020)
 /* warm-up of a decoder that joins inside a block: one chunk of seam window (>= the decode delay) + 1 020 bits for its fresh
  * start to be forgotten.  Measured (profiles/r02h_metric_convergence.txt): all 2^23 path metrics agree with those of a
@@ -194,7 +201,9 @@ static int vd_stream_any(vd_ctx *c, const unsigned char *s, int n, int d, unsign
   const int mode = e ? atoi(e) : 1;
   const int may = mode == 2 || (mode == 1 && c->front_done && *c->front_done);
   if (may && 5 * n >= 11 * VD_SHARE_WARM && !c->d[1]) {
+    if (getenv("ISEE3_CHAIN_D1_LOW")) setenv("V224HIP_STREAM_PRIORITY", "low", 1);      /* experiment */
     c->d[1] = create_viterbi224(c->len);
+    if (getenv("ISEE3_CHAIN_D1_LOW")) unsetenv("V224HIP_STREAM_PRIORITY");
     if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
   }
   if (!may || !c->d[1]) return v224hip_stream_decode(c->d[c->holder], s, n, d, o);
@@ -205,6 +214,8 @@ static int vd_stream(void *h, const unsigned char *s, int n, int d, unsigned cha
  * is then noticed within a few ms, and everything that is left goes to two decoders as ONE long block */
 static unsigned long vd_read_limit(void *h) {
   vd_ctx *c = h;
+  const char *e = getenv("ISEE3_CHAIN_SHARE");
+  if (e && atoi(e) == 2) return 0ul;
   return (c->front_done && !*c->front_done) ? 8192ul : 0ul;
 }
 static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigned char *o) {
@@ -225,6 +236,37 @@ static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigne
   v224hip_dev_free(ds); v224hip_dev_free(dout);
   return rc;
 }
+
+/* Progressive mode (the default when the capture's length is known): the whole symbol stream goes to
+ * v224hip_progressive_* as it arrives.  Decoder 0 works from the first symbol on; decoder 1 joins at the planned cut as soon
+ * as the symbols reach it -- ONE warm-up per capture instead of one per shared block, and both decoders busy for the second
+ * half of the front end's run as well (measured, scratch/starve.py: a second busy decoder slows pmdemod / symdemod by 25 %,
+ * not more, once every busy stream has its own compute pipe). */
+static int vd_prog_feed_any(vd_ctx *c, const unsigned char *s, int n, int d) {
+  if (!c->prog) {
+    if (c->expected >= 4 * VD_SHARE_WARM && !c->d[1]) {
+      c->d[1] = create_viterbi224(c->len);
+      if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
+    }
+    c->prog = v224hip_progressive_begin(c->d, c->d[1] ? 2 : 1, c->expected, d, VD_SHARE_WARM);
+    if (!c->prog) return -1;
+  }
+  return v224hip_progressive_feed(c->prog, s, n);
+}
+static int vd_prog_end_any(vd_ctx *c, long long n, int d, unsigned char *o) {
+  long long got = 0;
+  int redone = 0;
+  void *p = c->prog;
+  (void)d;
+  c->prog = NULL;
+  if (!p) return n == 0 ? 0 : -1;
+  if (v224hip_progressive_end(p, o, n, &got, &redone) != 0 || got != n) return -1;
+  if (getenv("V224HIP_VERBOSE")) fprintf(stderr, "isee3chain/vdecode: %lld bits, progressive on %d decoder(s), expected %lld, second part decoded again: %d\n",
+                                         n, c->d[1] ? 2 : 1, c->expected, redone);
+  return 0;
+}
+static int vd_prog_feed(void *h, const unsigned char *s, int n, int d) { TIMED(vd_prog_feed_any(h, s, n, d)); }
+static int vd_prog_end(void *h, long long n, int d, unsigned char *o) { TIMED(vd_prog_end_any(h, n, d, o)); }
 
 /* ---- block channel pmdemod -> symdemod: a ring of device slots, each one baseband block (N int16).  pmdemod acquires
  * a free slot, lets the engine write the block into it, commits it; symdemod takes views of committed slots in order
@@ -354,7 +396,7 @@ static int iq_next(void *p, int N, const int16_t **blk, int *is_dev) {
 
 typedef struct { pmdemod_opts o; iq_src src; blkchan *out; int rc; double ms; } pm_arg;
 typedef struct { symdemod_opts o; blkchan *in; FILE *out; int rc; double ms; volatile int *done; } sy_arg;
-typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; volatile int *front_done; } vd_arg;
+typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; volatile int *front_done; long long expected_bits; int progressive; } vd_arg;
 
 static void *pm_thread(void *p) {
   pm_arg *a = p;
@@ -381,9 +423,11 @@ static void *sy_thread(void *p) {
 static void *vd_thread(void *p) {
   vd_arg *a = p;
   vdecode_result r;
-  vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk, vd_whole, vd_read_limit };
+  vdecode_engine e = { vd_create, vd_init, vd_stream, vd_destroy, 2 * g_chunk, vd_whole, vd_read_limit, NULL, NULL };
+  if (a->progressive) { e.progressive_feed = vd_prog_feed; e.progressive_end = vd_prog_end; }
   t_stage_ms = 0;
   t_front_done = a->front_done;
+  t_expected_bits = a->expected_bits;
   a->rc = vdecode_run(&a->o, &e, a->fd_in, a->out, stderr, &r);
   a->ms = t_stage_ms;
   fflush(a->out);
@@ -412,9 +456,23 @@ static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   pa.o.binsize = co->binsize; pa.o.search_freq = co->search_freq; pa.o.search_width = co->search_width; pa.o.flip = co->flip;
   if (co->symrate) symdemod_set_symrate(&sa.o, co->symrate);   /* symdemod -c semantics; no getopt in a library that runs concurrent chains */
   va.o.decode_delay = co->decode_delay;
-  /* measured: at 30 k bits per capture a second decoder and the lost overlap with pmdemod / symdemod cost more than the
-   * split saves (72 vs 57 ms), so vdecode works block by block unless ISEE3_CHAIN_WHOLE=1 */
-  va.o.whole_input = getenv("ISEE3_CHAIN_WHOLE") ? atoi(getenv("ISEE3_CHAIN_WHOLE")) : 0;
+  /* how the Viterbi stage takes its symbols.  "progressive": one stream, fed as it arrives, second decoder joining at a
+   * cut placed from the expected number of bits (v224hip_progressive_*).  "block": block by block as the reference does,
+   * long blocks shared once the front end has finished (bits leave as they are decoded: the form for pipes).  "whole":
+   * wait for all symbols, then split (ISEE3_CHAIN_WHOLE=1; measured 72 vs 57 ms in round 1).  Default: progressive when
+   * the capture's length is known and the Viterbi decoder is what the run will wait for -- one decoder's time for the
+   * expected bits (1.18 us each) against the front end's (10 Gsamples/s + 0.3 ms per pmdemod block, both measured on
+   * MI355X); where the front end is the slower part (10 MS/s captures) one decoder keeps up with the symbols, a second one
+   * has nothing to gain, and block mode has the shorter tail (it never waits for a whole chunk). */
+  {
+    const char *m = getenv("ISEE3_CHAIN_MODE");
+    const double secs = src->iq ? (double)src->nsamples / co->samprate : 0;
+    const double nblocks = co->binsize > 0 ? secs * co->binsize : 0;          /* one block = 1 / binsize seconds (pmdemod.c:129-131) */
+    const double front_ms = (double)src->nsamples / 1e7 + 0.3 * nblocks;
+    va.expected_bits = (long long)(secs * sa.o.symrate / 2);
+    va.progressive = m ? !strcmp(m, "progressive") : (va.expected_bits >= 4 * VD_SHARE_WARM && 1.18e-3 * (double)va.expected_bits > front_ms);
+    va.o.whole_input = va.progressive || (m && !strcmp(m, "whole")) || (getenv("ISEE3_CHAIN_WHOLE") && atoi(getenv("ISEE3_CHAIN_WHOLE")));
+  }
   pa.o.quiet = sa.o.quiet = va.o.quiet = !co->verbose;
   pthread_once(&g_chunk_once, chunk_from_env);
   if (pipe(p2)) { snprintf(g_chain_err, sizeof g_chain_err, "pipe() failed"); return 2; }

@@ -146,7 +146,8 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
   /* whole-input mode: the engine can decode one long stream faster than many short blocks (two decoders on
    * consecutive parts), so when the caller says the input is finite and latency does not matter, pass 1 runs over ALL
    * of it first.  Same pairs, same decoder output, same pass 2: stdout is byte-identical either way. */
-  const int whole = o->whole_input && e->stream_decode_whole != NULL;
+  const int prog = o->whole_input && e->progressive_feed != NULL && e->progressive_end != NULL;
+  const int whole = o->whole_input && (prog || e->stream_decode_whole != NULL);
   size_t cap = INBLK / 2 + 1, flcap = INBLK / ISEE3_FRAMESYMBOLS + 2;
   unsigned char *inbuf = malloc(INBLK), *syms = malloc(2 * cap), *hard = malloc(cap), *dec = malloc(cap);
   char *obuf = malloc(whole ? 1 : cap);
@@ -187,12 +188,14 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
         if (!c) goto done;
         fl = c;
       }
+      const size_t np0 = np;
       np = pass1(o, &s1, inbuf, (size_t)got, delay, syms, hard, np, fl, &nfl);
+      if (prog && np > np0 && e->progressive_feed(vd, syms + 2 * np0, (int)(np - np0), delay) != 0) goto done;
     }
     free(dec); dec = malloc(np + 1);
     free(obuf); obuf = malloc(np + 1);
     if (!dec || !obuf) goto done;
-    if (np && e->stream_decode_whole(vd, syms, (long long)np, delay, dec) != 0) goto done;
+    if (np && (prog ? e->progressive_end(vd, (long long)np, delay, dec) : e->stream_decode_whole(vd, syms, (long long)np, delay, dec)) != 0) goto done;
     if (pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err) != 0) goto done;
     while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
   }

@@ -33,6 +33,11 @@ typedef struct {
   /* optional (may be NULL): how many input bytes the next read() may take at most (0 = no preference).  An engine that
      wants to look at its surroundings between blocks keeps them short for a while. */
   unsigned long (*read_limit)(void *h);
+  /* optional pair (both or neither; whole-input mode only): the one long stream is announced while it is being read --
+     feed() gets the symbols of the next nbits trellis steps as soon as pass 1 has paired them and may start decoding, end()
+     returns all nbits outputs under the contract of stream_decode_whole */
+  int   (*progressive_feed)(void *h, const unsigned char *syms, int nbits, int delay);
+  int   (*progressive_end)(void *h, long long nbits, int delay, unsigned char *out);
 } vdecode_engine;
 
 typedef struct {

@@ -61,21 +61,24 @@ extern "C" int isee3dsp_d2h(void *h, const void *d, size_t n) { return hipMemcpy
 static thread_local int t_share_stream = 0;
 static hipStream_t g_shared_stream[64];
 extern "C" void isee3dsp_share_stream(int on) { t_share_stream = on; }
-static hipError_t dsp_stream_create(hipStream_t *st, int *owned) {
-  int dev = 0;
-  *owned = 1;
-  if (t_share_stream && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!g_shared_stream[dev] && hipStreamCreateWithFlags(&g_shared_stream[dev], hipStreamNonBlocking) != hipSuccess) g_shared_stream[dev] = nullptr;
-    if (g_shared_stream[dev]) { *st = g_shared_stream[dev]; *owned = 0; return hipSuccess; }
-  }
+static hipError_t dsp_stream_create_one(hipStream_t *st) {
   int least = 0, greatest = 0;
   const char *e = getenv("ISEE3DSP_HIGH_PRIORITY");
   if (e && atoi(e) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
       hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
   (void)hipGetLastError();
   return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+static hipError_t dsp_stream_create(hipStream_t *st, int *owned) {
+  int dev = 0;
+  *owned = 1;
+  if (t_share_stream && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!g_shared_stream[dev] && dsp_stream_create_one(&g_shared_stream[dev]) != hipSuccess) g_shared_stream[dev] = nullptr;
+    if (g_shared_stream[dev]) { *st = g_shared_stream[dev]; *owned = 0; return hipSuccess; }
+  }
+  return dsp_stream_create_one(st);
 }
 
 static int grow(void **p, size_t *cap, size_t need) {

@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 #include "v224_common.h"
@@ -651,7 +652,15 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
   }
-  HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
+  {
+    // V224HIP_STREAM_PRIORITY=low|high: the decoder's stream at the lowest / highest priority the device offers (default:
+    // normal).  The chain creates its decoders "low": their back-to-back passes then let front-end kernels in first.
+    const char *pr = getenv("V224HIP_STREAM_PRIORITY");
+    int least = 0, greatest = 0;
+    if (pr && (pr[0] == 'l' || pr[0] == 'h') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+      HIPCHK(hipStreamCreateWithPriority(&v->st, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest));
+    else HIPCHK(hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking));
+  }
   if (tb_own_stream()) {
     if (getenv("V224HIP_TEST_GAP")) {      // experiment (scratch/pipe_scan.py): GAP other hardware queues created in between
       static hipStream_t dummies[64]; static int nd = 0;
@@ -1337,6 +1346,266 @@ extern "C" int v224hip_stream_decode_shared(void *const *decoders, int ndec, int
   return 0;
 fail:
   return -1;
+}
+
+// ---- a stream that is still arriving, on two decoders, exactly ---------------------------------------------------
+// The verified split (split_core) needs the whole stream up front; v224hip_stream_decode_shared pays one warm-up per
+// block.  Here the cut is PLANNED for an expected length when the stream begins: decoder 0 decodes [0, start1) as the
+// symbols come in, decoder 1 starts from a fresh init at start1 - warm as soon as the symbols reach that far and runs to
+// the end -- one warm-up for the whole stream, both decoders busy from then on.  The seam is verified exactly as in
+// split_core (relative metrics of all 2^23 states equal at start1 - check), with the same fall-back (decoder 0 simply
+// goes on past start1).  The expected length only places the cut: a shorter stream may never reach decoder 1's part, a
+// longer one makes its part longer.
+struct V224Prog {
+  V224 *d[2];
+  int ndec, delay;
+  long long chunk, check, warm, expected;
+  long long start1;                        // the cut; < 0 until it is fixed (and for good when can_split is false)
+  bool can_split;
+  uint8_t *d_syms, *d_out;
+  long long cap;                           // bits the device buffers hold
+  long long avail, a_pos, b_pos;           // bits uploaded; next bit of decoder 0 / of decoder 1 (b_pos starts at start1 - warm)
+  bool b_started, a_snapped, b_snapped;
+  // how far decoder 0 has really got (not just been told to go): events recorded behind its calls, polled oldest first
+  enum { NEV = 32 };
+  hipEvent_t ev[NEV]; long long ev_pos[NEV]; int ev_head, ev_count;
+  long long a_done;
+  double t_begin, t_cut, a_done_at_cut, avail_at_cut;      // V224HIP_VERBOSE report
+};
+static double prog_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+#define PROG_LOOK 6        /* chunks decoder 0 is told ahead of what it has finished while the cut is still open */
+
+static void prog_poll(V224Prog *g) {
+  while (g->ev_count > 0 && hipEventQuery(g->ev[g->ev_head]) == hipSuccess) {
+    g->a_done = g->ev_pos[g->ev_head];
+    g->ev_head = (g->ev_head + 1) % V224Prog::NEV; g->ev_count--;
+  }
+  (void)hipGetLastError();                 // hipErrorNotReady is not an error here
+}
+static void prog_mark(V224Prog *g) {
+  if (g->ev_count >= V224Prog::NEV) return;                   // all in flight: the next poll will see an older one first
+  const int i = (g->ev_head + g->ev_count) % V224Prog::NEV;
+  if (!g->ev[i] && hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess) { g->ev[i] = nullptr; return; }
+  if (hipEventRecord(g->ev[i], g->d[0]->st) != hipSuccess) return;
+  g->ev_pos[i] = g->a_pos; g->ev_count++;
+}
+
+static int prog_grow(V224Prog *g, long long need) {
+  if (need <= g->cap) return 0;
+  long long ncap = g->cap * 2 > need ? g->cap * 2 : need + 65536;
+  uint8_t *ns = nullptr, *no = nullptr;
+  for (int j = 0; j < g->ndec; j++) if (hipStreamSynchronize(g->d[j]->st) != hipSuccess) return -1;
+  if (hipMalloc(&ns, 2 * (size_t)ncap) != hipSuccess || hipMalloc(&no, (size_t)ncap) != hipSuccess) { (void)hipFree(ns); (void)hipGetLastError(); return -1; }
+  if (hipMemcpy(ns, g->d_syms, 2 * (size_t)g->avail, hipMemcpyDeviceToDevice) != hipSuccess ||
+      hipMemcpy(no, g->d_out, (size_t)g->cap, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(ns); (void)hipFree(no); return -1; }
+  (void)hipFree(g->d_syms); (void)hipFree(g->d_out);
+  g->d_syms = ns; g->d_out = no; g->cap = ncap;
+  return 0;
+}
+
+static int prog_snapshot(V224 *v, int side) {
+  ensure_layout(v, 1);
+  ensure_min_valid(v);
+  k_snapshot_rel<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[v->cur], v->ds, v->pass, v->snap[side]);
+  HIPCHK(hipEventRecord(v->ev_snap[side], v->st));
+  return 0;
+fail:
+  return -1;
+}
+
+// enqueue what the symbols known so far allow.  Unless `final`, a decoder advances in whole chunks only (a ragged call
+// would cost remainder passes and a switch of the metric order in the middle of the stream).
+//
+// Where the cut goes is decided when decoder 1 can start, not before: if decoder 0 has finished a_done bits by then
+// and both run at the same (pair) rate from then on, they finish together when x - a_done = expected - x + warm, i.e.
+// x = (expected + warm + a_done) / 2 -- later than the middle by half of what decoder 0 managed alone.  Symbols that
+// arrive no faster than one decoder decodes push x to the end (no second part: nothing to gain); symbols that are all
+// there at once give the even split of split_core.  Until the cut is fixed decoder 0 is only told PROG_LOOK chunks ahead
+// of what it has finished, so that its snapshot at x - check can still be placed.
+static int prog_advance(V224Prog *g, bool final) {
+  const long long q = g->chunk;
+  prog_poll(g);
+  if (g->can_split && g->start1 < 0) {
+    if (final) g->can_split = false;                           // everything is known and decoder 1 never got going
+    else {
+      long long x = (g->expected + g->warm + g->a_done) / 2 / q * q;
+      if (x - g->check < g->a_pos) x = (g->a_pos + g->check + q - 1) / q * q;      // (cannot happen with PROG_LOOK < warm / chunk)
+      if (x + 2 * q > g->expected) g->can_split = false;       // what would be left for decoder 1 is not worth a warm-up
+      else if (g->avail >= x - g->warm + q && x - g->warm >= 0) {
+        g->start1 = x; g->b_pos = x - g->warm;
+        g->t_cut = prog_now(); g->a_done_at_cut = (double)g->a_done; g->avail_at_cut = (double)g->avail;
+      }
+    }
+  }
+  // decoder 0: [0, start1) -- or everything when there is no second part -- with its snapshot at start1 - check
+  for (;;) {
+    long long lim = g->avail;
+    if (g->start1 >= 0) {
+      if (lim > g->start1) lim = g->start1;
+      if (!g->a_snapped && lim > g->start1 - g->check) lim = g->start1 - g->check;
+    } else if (g->can_split && lim > g->a_done + PROG_LOOK * q) lim = (g->a_done + PROG_LOOK * q) / q * q;
+    long long n = lim - g->a_pos;
+    if (!final || lim < g->avail) n = n / q * q;               // (the planned boundaries are chunk multiples anyway)
+    if (n > 0) {
+      if (n > 0x40000000) n = 0x40000000 / q * q;
+      if (v224hip_stream_decode_dev(g->d[0], g->d_syms + 2 * g->a_pos, (int)n, g->delay, g->d_out + g->a_pos) != 0) return -1;
+      g->a_pos += n;
+      prog_mark(g);
+    }
+    if (g->start1 >= 0 && !g->a_snapped && g->a_pos == g->start1 - g->check) {
+      if (prog_snapshot(g->d[0], 0) != 0) return -1;
+      g->a_snapped = true;
+      continue;
+    }
+    if (n <= 0) break;
+  }
+  if (g->start1 < 0 || (final && g->avail <= g->start1)) return 0;       // no second part (planned, or reached)
+  // decoder 1: fresh start at start1 - warm, snapshot at start1 - check, then its part to the end
+  for (;;) {
+    if (g->avail <= g->b_pos) break;
+    if (!g->b_started) {
+      if (g->avail - g->b_pos < q && !final) break;
+      if (init_viterbi224(g->d[1], 0) != 0) return -1;
+      g->b_started = true;
+    }
+    long long lim = g->avail;
+    uint8_t *out;
+    if (!g->b_snapped) { if (lim > g->start1 - g->check) lim = g->start1 - g->check; out = g->d[1]->warmout + (g->b_pos - (g->start1 - g->warm)); }
+    else if (g->b_pos < g->start1) { if (lim > g->start1) lim = g->start1; out = g->d[1]->warmout + (g->b_pos - (g->start1 - g->warm)); }
+    else out = g->d_out + g->b_pos;
+    long long n = lim - g->b_pos;
+    if (!final || lim < g->avail) n = n / q * q;
+    if (n > 0) {
+      if (n > 0x40000000) n = 0x40000000 / q * q;
+      if (v224hip_stream_decode_dev(g->d[1], g->d_syms + 2 * g->b_pos, (int)n, g->delay, out) != 0) return -1;
+      g->b_pos += n;
+    }
+    if (!g->b_snapped && g->b_pos == g->start1 - g->check) {
+      if (prog_snapshot(g->d[1], 1) != 0) return -1;
+      g->b_snapped = true;
+      continue;
+    }
+    if (n <= 0) break;
+  }
+  return 0;
+}
+
+extern "C" void v224hip_progressive_abort(void *h) {
+  V224Prog *g = (V224Prog *)h;
+  if (!g) return;
+  for (int j = 0; j < g->ndec; j++) if (g->d[j]) (void)hipStreamSynchronize(g->d[j]->st);
+  for (int i = 0; i < V224Prog::NEV; i++) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+  (void)hipFree(g->d_syms); (void)hipFree(g->d_out);
+  delete g;
+}
+
+extern "C" void *v224hip_progressive_begin(void *const *decoders, int ndec, long long expected_bits, int delay, int warm_bits) {
+  V224Prog *g = nullptr;
+  if (!decoders || ndec < 1 || !decoders[0] || delay <= 0 || expected_bits < 0) {
+    snprintf(g_err, sizeof g_err, "progressive_begin: bad argument");
+    return nullptr;
+  }
+  if (ndec > 2) ndec = 2;                                      // two decoders are all a CU can hold
+  V224 *v0 = (V224 *)decoders[0];
+  for (int j = 0; j < ndec; j++) {
+    V224 *v = (V224 *)decoders[j];
+    if (!v || v->dev != v0->dev || v->chunk != v0->chunk || v->len < delay + (v->st2 == v->st ? 1 : 2) * v->chunk) {
+      snprintf(g_err, sizeof g_err, "progressive_begin: decoder %d is NULL, on another device, has another chunk size or a short ring", j);
+      return nullptr;
+    }
+  }
+  g = new V224Prog();
+  g->ndec = ndec; g->delay = delay;
+  g->d[0] = v0; g->d[1] = ndec > 1 ? (V224 *)decoders[1] : nullptr;
+  g->chunk = v0->chunk;
+  g->check = ((long long)delay + g->chunk - 1) / g->chunk * g->chunk;
+  g->warm = ((long long)warm_bits + g->chunk - 1) / g->chunk * g->chunk;
+  if (g->warm < g->check + 2 * g->chunk) g->warm = g->check + 2 * g->chunk;
+  g->expected = expected_bits;
+  g->t_begin = prog_now();
+  g->start1 = -1; g->b_pos = 0;
+  g->can_split = ndec > 1 && (expected_bits + g->warm) / 2 / g->chunk * g->chunk >= g->warm + g->chunk;     // as split_core: worth two parts at all?
+  HIPCHK(hipSetDevice(v0->dev));
+  g->cap = expected_bits + expected_bits / 8 + 65536;
+  HIPCHK(hipMalloc(&g->d_syms, 2 * (size_t)g->cap));
+  HIPCHK(hipMalloc(&g->d_out, (size_t)g->cap));
+  if (g->can_split) {
+    V224 *a = g->d[0], *b = g->d[1];
+    if (!a->snap[0]) HIPCHK(hipMalloc(&a->snap[0], sizeof(uint16_t) * V224_NSTATES));
+    if (!a->ev_snap[0]) HIPCHK(hipEventCreateWithFlags(&a->ev_snap[0], hipEventDisableTiming));
+    if (!b->snap[1]) HIPCHK(hipMalloc(&b->snap[1], sizeof(uint16_t) * V224_NSTATES));
+    if (!b->ev_snap[1]) HIPCHK(hipEventCreateWithFlags(&b->ev_snap[1], hipEventDisableTiming));
+    if (ensure_cap(&b->warmout, &b->warmout_cap, (size_t)g->warm) != 0) { snprintf(g_err, sizeof g_err, "progressive_begin: warm-up buffer allocation failed"); goto fail; }
+  }
+  if (init_viterbi224(v0, 0) != 0) goto fail;
+  return g;
+fail:
+  v224hip_progressive_abort(g);
+  return nullptr;
+}
+
+extern "C" int v224hip_progressive_feed(void *h, const uint8_t *syms, int nbits) {
+  V224Prog *g = (V224Prog *)h;
+  if (!g || nbits < 0 || (nbits > 0 && !syms)) { snprintf(g_err, sizeof g_err, "progressive_feed: bad argument"); return -1; }
+  if (nbits == 0) return 0;
+  HIPCHK(hipSetDevice(g->d[0]->dev));
+  if (prog_grow(g, g->avail + nbits) != 0) { snprintf(g_err, sizeof g_err, "progressive_feed: cannot grow the symbol buffer"); return -1; }
+  HIPCHK(hipMemcpy(g->d_syms + 2 * g->avail, syms, 2 * (size_t)nbits, hipMemcpyHostToDevice));   // done when it returns: both streams may read it
+  g->avail += nbits;
+  return prog_advance(g, false);
+fail:
+  return -1;
+}
+
+// All symbols are in: finish both decoders, check the seam, hand out all avail bits (out[] = what one decoder's
+// v224hip_stream_decode of the whole stream writes).  *redone = 1 when the seam check failed and decoder 0 decoded the
+// second part again.  The handle is gone afterwards, whatever the result.
+extern "C" int v224hip_progressive_end(void *h, uint8_t *out, long long cap, long long *nbits_out, int *redone) {
+  V224Prog *g = (V224Prog *)h;
+  int rc = -1, fb = 0;
+  unsigned cnt = 0;
+  if (redone) *redone = 0;
+  if (nbits_out) *nbits_out = 0;
+  if (!g) return -1;
+  if (!out || cap < g->avail) { snprintf(g_err, sizeof g_err, "progressive_end: output buffer too small"); goto done; }
+  HIPCHK(hipSetDevice(g->d[0]->dev));
+  {
+    const double t_end = prog_now();
+    prog_poll(g);
+    const long long a_done_end = g->a_done;
+    if (prog_advance(g, true) != 0) goto done;
+    if (getenv("V224HIP_VERBOSE")) {
+      for (int j = 0; j < g->ndec; j++) (void)hipStreamSynchronize(g->d[j]->st);
+      fprintf(stderr, "v224hip progressive: %lld bits (expected %lld); cut at %lld fixed %.2f ms after begin (decoder 0 had finished %.0f, %.0f known); "
+                      "end() called at %.2f ms with decoder 0 at %lld; all decoded at %.2f ms\n", g->avail, g->expected, g->start1,
+              g->start1 >= 0 ? g->t_cut - g->t_begin : -1.0, g->a_done_at_cut, g->avail_at_cut, t_end - g->t_begin, a_done_end, prog_now() - g->t_begin);
+    }
+  }
+  if (g->start1 >= 0 && g->avail > g->start1) {
+    // (decoder 0 stands at start1, both snapshots are enqueued: avail > start1 > start1 - check)
+    V224 *a = g->d[0], *b = g->d[1];
+    unsigned *d_cnt = (unsigned *)(a->dmisc + 1024);
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned), a->st));
+    HIPCHK(hipStreamWaitEvent(a->st, b->ev_snap[1], 0));
+    k_count_diff<<<V224_NSTATES / 8 / 256, 256, 0, a->st>>>(reinterpret_cast<const uint4 *>(a->snap[0]), reinterpret_cast<const uint4 *>(b->snap[1]), d_cnt);
+    HIPCHK(hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, a->st));
+    HIPCHK(hipStreamSynchronize(a->st));
+    if (getenv("V224HIP_SPLIT_FORCE_FALLBACK")) cnt = 1;                               // test hook, as in split_core
+    if (cnt != 0) {
+      fb = 1;
+      HIPCHK(hipStreamSynchronize(b->st));                                             // its writes into d_out must not land later
+      if (v224hip_stream_decode_dev(a, g->d_syms + 2 * g->start1, (int)(g->avail - g->start1), g->delay, g->d_out + g->start1) != 0) goto done;
+    }
+  }
+  for (int j = 0; j < g->ndec; j++) HIPCHK(hipStreamSynchronize(g->d[j]->st));
+  if (g->avail) HIPCHK(hipMemcpy(out, g->d_out, (size_t)g->avail, hipMemcpyDeviceToHost));
+  if (nbits_out) *nbits_out = g->avail;
+  if (redone) *redone = fb;
+  rc = 0;
+done:
+fail:
+  v224hip_progressive_abort(g);
+  return rc;
 }
 
 extern "C" int v224hip_stream_decode(void *p, const uint8_t *syms, int nbits, int delay, uint8_t *out) {

@@ -4,6 +4,7 @@
  * TEST INFRASTRUCTURE ONLY. */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../../isee3-decoder_amd/cli/vdecode_core.h"
 #include "../../oracle/oracle.h"
 
@@ -24,12 +25,30 @@ static int eng_whole(void *h, const unsigned char *syms, long long nbits, int de
 static void eng_destroy(void *h) { orc_v224_delete(h); }
 static unsigned long eng_limit(void *h) { (void)h; return getenv("VDECODE_TEST_LIMIT") ? strtoul(getenv("VDECODE_TEST_LIMIT"), NULL, 10) : 0; }
 
+/* progressive pair (VDECODE_WHOLE=2): decode each piece when it is announced, hand everything out at the end */
+static unsigned char *pbuf; static long long pn, pcap, pcalls;
+static int eng_feed(void *h, const unsigned char *syms, int nbits, int delay) {
+  if (pn + nbits > pcap) { pcap = 2 * (pn + nbits) + 64; pbuf = realloc(pbuf, (size_t)pcap); if (!pbuf) return -1; }
+  pcalls++;
+  int rc = eng_stream(h, syms, nbits, delay, pbuf + pn);
+  pn += nbits;
+  return rc;
+}
+static int eng_end(void *h, long long nbits, int delay, unsigned char *out) {
+  (void)h; (void)delay;
+  if (nbits != pn) return -1;
+  memcpy(out, pbuf, (size_t)nbits);
+  fprintf(stderr, "PROGRESSIVE feeds=%lld\n", pcalls);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   vdecode_opts o;
   vdecode_result r;
   vdecode_parse_args(&o, argc, argv);
-  vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 0, eng_whole, eng_limit };
+  vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 0, eng_whole, eng_limit, NULL, NULL };
   o.whole_input = getenv("VDECODE_WHOLE") && atoi(getenv("VDECODE_WHOLE"));
+  if (o.whole_input && atoi(getenv("VDECODE_WHOLE")) == 2) { e.progressive_feed = eng_feed; e.progressive_end = eng_end; }
   int rc = vdecode_run(&o, &e, 0, stdout, stderr, &r);
   fprintf(stderr, "RESULT bits=%llu symerrs=%llu flips=%d\n", r.bits_out, r.symerrs_total, r.flips);
   return rc ? 2 : 0;

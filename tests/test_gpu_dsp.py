@@ -206,6 +206,55 @@ def test_in_process_chain_equals_three_stage_pipeline(pkg):
         assert pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024") == bits
 
 
+def test_chain_viterbi_stage_modes_give_the_same_bits(pkg, monkeypatch):
+    """The chain's Viterbi stage can take its symbols block by block (long blocks shared between two decoders at the end),
+    progressively (one stream fed as it arrives, second decoder joining at the planned cut, v224hip_progressive_*) or
+    whole (wait for all, then split): the decoded bits are the same, with the capture in host memory and in HBM."""
+    fs = 32768.0
+    iq, sent = orc.gen_iq(93, fs, 40.0, fc_hz=2345.6, amp=3000.0, cn0_dbhz=48.0)
+    d_iq = pkg.DeviceBuffer.from_numpy(iq)
+    got = {}
+    for mode in ("block", "progressive", "whole"):
+        monkeypatch.setenv("ISEE3_CHAIN_MODE", mode)
+        got[mode] = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
+        assert pkg.run_chain(d_iq, samprate=fs, binsize=1.0, symrate="1024") == got[mode], mode
+    assert got["block"] == got["progressive"] == got["whole"] and len(got["block"]) > 19000
+    monkeypatch.setenv("V224HIP_SPLIT_FORCE_FALLBACK", "1")          # the redo path inside the chain
+    monkeypatch.setenv("ISEE3_CHAIN_MODE", "progressive")
+    assert pkg.run_chain(d_iq, samprate=fs, binsize=1.0, symrate="1024") == got["block"]
+    d_iq.free()
+
+
+def test_chain_beside_a_busy_decoder_thread(pkg):
+    """A chain run while another thread of the process keeps a decoder of its own busy (own stream, same GPU): same bits."""
+    import threading
+    fs = 32768.0
+    iq, sent = orc.gen_iq(94, fs, 12.0, fc_hz=-1234.5, amp=3000.0, cn0_dbhz=48.0)
+    want = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
+    syms, _ = orc.gen_coded_stream(9900, 60_000, 3.0, 24.0, 0)
+    dec = pkg.Viterbi224(200 + 2040)
+    dec.init(0)
+    ref = dec.stream_decode(syms, 200)
+    stop, bad = [False], []
+
+    def busy():
+        while not stop[0]:
+            dec.init(0)
+            if not np.array_equal(dec.stream_decode(syms, 200), ref):
+                bad.append(1)
+
+    th = threading.Thread(target=busy)
+    th.start()
+    try:
+        for _ in range(3):
+            assert pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024") == want
+    finally:
+        stop[0] = True
+        th.join()
+    assert not bad
+    dec.close()
+
+
 def test_stress_10msps_block_and_window(pkg):
     """BASELINE configs[4] shapes: 10 MS/s, 1 Hz bins => N = 2^23 FFT blocks, 9 760 samples per symbol
     (timesearch over 9 761 offsets).  One pmdemod block and one symdemod window against the oracle."""

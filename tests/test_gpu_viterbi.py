@@ -606,3 +606,56 @@ def test_stream_blocks_shared_between_two_decoders(pkg, chunk, warms):
     assert np.array_equal(decs[holder].stream_decode(tail, delay), one.stream_decode(tail, delay))
     for d in decs + [one]:
         d.close()
+
+
+def _progressive(pkg, decs, syms, nbits, expected, delay, pieces, warm=3060):
+    p = pkg.ProgressiveDecode(decs, expected, delay, warm)
+    pos = 0
+    for n in pieces:
+        n = min(n, nbits - pos)
+        if n <= 0:
+            break
+        p.feed(syms[2 * pos:2 * (pos + n)])
+        pos += n
+    while pos < nbits:
+        n = min(4096, nbits - pos)
+        p.feed(syms[2 * pos:2 * (pos + n)])
+        pos += n
+    return p.end()
+
+
+@pytest.mark.parametrize("case", ["as_expected", "shorter_than_the_cut", "just_past_the_cut", "longer_than_expected",
+                                  "too_short_to_split", "one_decoder", "noise", "forced_redo"])
+def test_progressive_two_decoder_stream_equals_one_decoder(pkg, case, monkeypatch):
+    """v224hip_progressive_*: a stream fed piece by piece while two decoders work on it (cut planned for an EXPECTED length,
+    one warm-up, seam verified) == v224hip_stream_decode of the whole stream on one decoder, byte for byte: ragged pieces,
+    a stream that ends before / just after / far beyond the planned cut, a plan too short to split, a single decoder,
+    pure noise across the seam, and the redo path forced."""
+    delay, chunk = 200, 1020
+    nbits, expected = {"as_expected": (60_001, 60_000), "shorter_than_the_cut": (25_003, 60_000),
+                       "just_past_the_cut": (31_700, 60_000), "longer_than_expected": (90_010, 60_000),
+                       "too_short_to_split": (7_000, 7_000), "one_decoder": (40_000, 40_000),
+                       "noise": (50_000, 50_000), "forced_redo": (50_000, 50_000)}[case]
+    syms, _ = orc.gen_coded_stream(9800, nbits, 2.5, 24.0, 2)
+    if case == "noise":
+        syms[2 * 15_000:2 * 45_000] = np.random.default_rng(5).integers(0, 256, 60_000, dtype=np.uint8)
+    if case == "forced_redo":
+        monkeypatch.setenv("V224HIP_SPLIT_FORCE_FALLBACK", "1")
+    one = pkg.Viterbi224(delay + 2 * chunk)
+    decs = [pkg.Viterbi224(delay + 2 * chunk) for _ in range(1 if case == "one_decoder" else 2)]
+    for d in decs + [one]:
+        d.set_option("chunk", chunk)
+    one.init(0)
+    want = one.stream_decode(syms, delay)
+    rng = np.random.default_rng(6)
+    pieces = [int(x) for x in rng.integers(1, 3000, 200)] + [1, 2, 3]
+    got, redone = _progressive(pkg, decs, syms, nbits, expected, delay, pieces)
+    assert len(got) == nbits and np.array_equal(got, want)
+    assert redone == (1 if case == "forced_redo" else redone)
+    if case in ("as_expected", "longer_than_expected", "just_past_the_cut"):
+        assert redone == 0
+    # the decoders are ordinary decoders again afterwards, and a second progressive run on them works
+    got2, _ = _progressive(pkg, decs, syms, min(nbits, 20_000), 20_000, delay, [777] * 100)
+    assert np.array_equal(got2, want[:min(nbits, 20_000)])
+    for d in decs + [one]:
+        d.close()

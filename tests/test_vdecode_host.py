@@ -34,17 +34,19 @@ def harness():
     return exe
 
 
-@pytest.mark.parametrize("whole", ["0", "1", "limit"], ids=["blockwise", "whole_input", "blockwise_read_limit_777"])
+@pytest.mark.parametrize("whole", ["0", "1", "2", "limit"], ids=["blockwise", "whole_input", "progressive", "blockwise_read_limit_777"])
 @pytest.mark.parametrize("name", _names())
 def test_host_logic_with_oracle_engine(harness, name, whole):
     """block by block as the input arrives (the reference's way), or pass 1 over ALL input first and one engine call
-    (whole-input mode, what the chain and `vdecode < file` use): the same stdout"""
+    (whole-input mode, what `vdecode < file` uses), or the engine fed with the paired symbols while they are read and
+    asked for everything at the end (progressive, what the chain uses): the same stdout"""
     z = np.load(G)
     p = subprocess.run([harness, "-q"] + _args(z, name), input=z[name + "/syms"].tobytes(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=600,
-                       env=dict(os.environ, VDECODE_WHOLE="1" if whole == "1" else "0",
+                       env=dict(os.environ, VDECODE_WHOLE=whole if whole in ("1", "2") else "0",
                                 **({"VDECODE_TEST_LIMIT": "777"} if whole == "limit" else {})))
     assert p.stdout == z[name + "/stdout"].tobytes()
+    assert (b"PROGRESSIVE feeds=" in p.stderr) == (whole == "2")
     if name == "flip":
         assert b"flips=1" in p.stderr
 
@@ -65,13 +67,13 @@ def status_lines(stderr_bytes):
     """stderr of a vdecode run without the program name (argv[0] differs) and without this harness's own RESULT line"""
     out = []
     for ln in stderr_bytes.decode().splitlines():
-        if ln.startswith("RESULT ") or not ln.strip():
+        if ln.startswith("RESULT ") or ln.startswith("PROGRESSIVE ") or not ln.strip():
             continue
         out.append(ln.split(": ", 1)[1] if ": " in ln else ln)
     return out
 
 
-@pytest.mark.parametrize("whole", ["0", "1"], ids=["blockwise", "whole_input"])
+@pytest.mark.parametrize("whole", ["0", "1", "2"], ids=["blockwise", "whole_input", "progressive"])
 @pytest.mark.parametrize("name", [str(n) for n in np.load(E)["names"]])
 def test_reencode_symbol_error_statistic_matches_reference_stderr(harness, name, whole):
     """vdecode.c:159-184: the decoded bits are re-encoded and compared with the hard-sliced received symbols; the tally
