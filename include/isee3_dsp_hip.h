@@ -21,9 +21,10 @@ extern "C" {
 
 const char *isee3dsp_last_error(void);
 int isee3dsp_set_device(int dev);
-/* Handles created by the calling thread while this is on share ONE stream per device instead of getting one each (the
- * in-process chain turns it on: pmdemod + symdemod + two Viterbi decoders must fit the GPU's four compute pipes). */
-void isee3dsp_share_stream(int on);
+/* Which stream the handles created by the calling thread from now on use: 0 one of their own each (default), 1 ONE
+ * stream per device shared by all such handles, 2 the null stream.  The in-process chain uses 1 for pmdemod and 2 for
+ * symdemod: together with its two Viterbi decoders that is four busy streams on the GPU's four compute pipes. */
+void isee3dsp_share_stream(int mode);
 
 /* device / pinned host memory for C callers that keep streams resident in HBM (used by libisee3chain.so) */
 void *isee3dsp_dev_alloc(size_t bytes);

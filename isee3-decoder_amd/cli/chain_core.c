@@ -97,7 +97,10 @@ static void pm_destroy(void *p) {
 static void *sy_create(int n) {
   dsp_ctx *c = malloc(sizeof *c);
   if (!c) return NULL;
-  isee3dsp_share_stream(1);
+  /* symdemod's kernels go to the NULL stream, pmdemod's to the front-end stream: with the two decoders that makes four busy
+   * streams on hardware queues 0 (the null stream's, always there) .. 3 = one per compute pipe, whatever the process created
+   * before (isee3_dsp_hip.h, isee3dsp_share_stream).  ISEE3_CHAIN_SY_NULL=0: both stages on the one front-end stream. */
+  { const char *e = getenv("ISEE3_CHAIN_SY_NULL"); isee3dsp_share_stream(e && atoi(e) == 0 ? 1 : 2); }
   c->n = n; c->h = pool_take(g_sy_pool, n);
   if (c->h) symd_store_reset(c->h);                 /* a kept handle: its window buffer starts out zero again */
   else c->h = symd_create(n);

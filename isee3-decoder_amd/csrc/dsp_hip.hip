@@ -50,14 +50,16 @@ extern "C" void isee3dsp_dev_free(void *d) { if (d) (void)hipFree(d); }
 extern "C" int isee3dsp_h2d(void *d, const void *h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 extern "C" int isee3dsp_d2h(void *h, const void *d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 
-// Stream of a front-end handle: its own, or -- for handles created while isee3dsp_share_stream(1) is in force in the
-// creating thread -- ONE stream per device shared by all such handles (never destroyed).  Why share: MI355X feeds compute
-// queues through four hardware pipes; HIP's hardware queues land on them in creation order (queue 0 = the null stream),
-// and only queues 1..3 run side by side with each other without one starving the other (v224_hip.hip, tb_own_stream).  The
-// in-process chain needs two Viterbi decoders and the front end at the same time: with pmdemod and symdemod on one
-// stream that is three.  Their kernels are short and the two stages' host threads synchronise on results anyway.
-// (ISEE3DSP_HIGH_PRIORITY=1 asks for the highest stream priority for own streams; off by default: with priority queues
-// in the mix the pairing of streams and hardware queues became even less predictable.)
+// Stream of a front-end handle, chosen by isee3dsp_share_stream(mode) in the creating thread: 0 its own (default); 1 ONE
+// stream per device shared by all such handles (never destroyed); 2 the null stream.  Why: MI355X feeds compute queues
+// through four hardware pipes; HIP's hardware queues land on them in creation order (queue 0 = the null stream's), and
+// only queues 0..3 run side by side without one starving the other (v224_hip.hip / DESIGN.md "One stream per decoder").
+// The in-process chain has four things to run at once -- two Viterbi decoders, pmdemod, symdemod: decoders on their own
+// streams, pmdemod on the shared front-end stream (mode 1), symdemod on the null stream (mode 2), whose queue exists in
+// every process and is otherwise idle in this library.  All other streams here are hipStreamNonBlocking, so nothing
+// synchronises with the null stream implicitly; a host application that keeps the null stream busy itself shares it with
+// symdemod's short kernels (correct, slower): ISEE3_CHAIN_SY_NULL=0 then puts both stages on the mode-1 stream.
+// (ISEE3DSP_HIGH_PRIORITY=1 asks for the highest stream priority for created streams; measured: no effect.)
 static thread_local int t_share_stream = 0;
 static hipStream_t g_shared_stream[64];
 extern "C" void isee3dsp_share_stream(int on) { t_share_stream = on; }
@@ -72,6 +74,7 @@ static hipError_t dsp_stream_create_one(hipStream_t *st) {
 static hipError_t dsp_stream_create(hipStream_t *st, int *owned) {
   int dev = 0;
   *owned = 1;
+  if (t_share_stream == 2) { *st = nullptr; *owned = 0; return hipSuccess; }       // the null stream
   if (t_share_stream && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -390,7 +393,7 @@ extern "C" void symd_destroy(void *p) {
   Symd *h = (Symd *)p;
   if (!h) return;
   (void)hipSetDevice(h->dev);
-  if (h->st) { (void)hipStreamSynchronize(h->st); if (h->own_st) (void)hipStreamDestroy(h->st); }
+  (void)hipStreamSynchronize(h->st); if (h->st && h->own_st) (void)hipStreamDestroy(h->st);
   (void)hipFree(h->d_s); (void)hipFree(h->d_s2); (void)hipFree(h->d_P); (void)hipFree(h->d_blk); (void)hipFree(h->d_idx);
   (void)hipFree(h->d_e); (void)hipFree(h->d_out); (void)hipFree(h->d_sym); (void)hipFree(h->d_part); (void)hipFree(h->d_terms);
   (void)hipFree(h->d_flag);
@@ -992,7 +995,7 @@ extern "C" void pmd_destroy(void *p) {
   Pmd *h = (Pmd *)p;
   if (!h) return;
   (void)hipSetDevice(h->dev);
-  if (h->st) { (void)hipStreamSynchronize(h->st); if (h->own_st) (void)hipStreamDestroy(h->st); }
+  (void)hipStreamSynchronize(h->st); if (h->st && h->own_st) (void)hipStreamDestroy(h->st);
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red);
@@ -1204,7 +1207,7 @@ extern "C" void isync_destroy(void *p) {
   Isync *h = (Isync *)p;
   if (!h) return;
   (void)hipSetDevice(h->dev);
-  if (h->st) { (void)hipStreamSynchronize(h->st); if (h->own_st) (void)hipStreamDestroy(h->st); }
+  (void)hipStreamSynchronize(h->st); if (h->st && h->own_st) (void)hipStreamDestroy(h->st);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->V); (void)hipFree(h->D); (void)hipFree(h->R); (void)hipFree(h->tmp); (void)hipFree(h->d_s); (void)hipFree(h->d_red);
   free(h);
