@@ -204,9 +204,7 @@ static int vd_stream_any(vd_ctx *c, const unsigned char *s, int n, int d, unsign
   const int mode = e ? atoi(e) : 1;
   const int may = mode == 2 || (mode == 1 && c->front_done && *c->front_done);
   if (may && 5 * n >= 11 * VD_SHARE_WARM && !c->d[1]) {
-    if (getenv("ISEE3_CHAIN_D1_LOW")) setenv("V224HIP_STREAM_PRIORITY", "low", 1);      /* experiment */
     c->d[1] = create_viterbi224(c->len);
-    if (getenv("ISEE3_CHAIN_D1_LOW")) unsetenv("V224HIP_STREAM_PRIORITY");
     if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
   }
   if (!may || !c->d[1]) return v224hip_stream_decode(c->d[c->holder], s, n, d, o);

@@ -654,7 +654,7 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   }
   {
     // V224HIP_STREAM_PRIORITY=low|high: the decoder's stream at the lowest / highest priority the device offers (default:
-    // normal).  The chain creates its decoders "low": their back-to-back passes then let front-end kernels in first.
+    // normal).  An experiment knob: measured in the chain (decoders low and / or front end high), no effect on any stage.
     const char *pr = getenv("V224HIP_STREAM_PRIORITY");
     int least = 0, greatest = 0;
     if (pr && (pr[0] == 'l' || pr[0] == 'h') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
