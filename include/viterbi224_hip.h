@@ -74,7 +74,8 @@ int v224hip_stream_decode_shared(void *const *decoders, int ndec, int *holder, c
  * trickle in, never when one decoder keeps up with them.  end() finishes, verifies the seam as above (decoder 0 decodes
  * the second part again if the check fails: *redone = 1), writes all bits -- exactly what one decoder's
  * v224hip_stream_decode() of the whole stream writes -- and releases the handle (also on failure).  A wrong expectation
- * only misplaces the cut.  Both decoders: same device and chunk, len >= delay + chunk; they are (re-)initialised by these
+ * only misplaces the cut.  warm_bits is raised to the seam window (delay rounded up to chunks) + one chunk.  Both decoders:
+ * same device and chunk, len >= delay + chunk; they are (re-)initialised by these
  * calls.  NULL / -1 on failure (v224hip_last_error()); abort() drops a handle without finishing. */
 void *v224hip_progressive_begin(void *const *decoders, int ndec, long long expected_bits, int delay, int warm_bits);
 int   v224hip_progressive_feed(void *h, const uint8_t *syms, int nbits);

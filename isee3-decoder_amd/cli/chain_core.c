@@ -243,13 +243,14 @@ static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigne
  * as the symbols reach it -- ONE warm-up per capture instead of one per shared block, and both decoders busy for the second
  * half of the front end's run as well (measured, scratch/starve.py: a second busy decoder slows pmdemod / symdemod by 25 %,
  * not more, once every busy stream has its own compute pipe). */
+#define VD_PROG_WARM (2 * CHAIN_CHUNK)       /* seam window (one chunk >= the decode delay of 200) + one chunk of forgetting */
 static int vd_prog_feed_any(vd_ctx *c, const unsigned char *s, int n, int d) {
   if (!c->prog) {
     if (c->expected >= 4 * VD_SHARE_WARM && !c->d[1]) {
       c->d[1] = create_viterbi224(c->len);
       if (c->d[1]) v224hip_set_option(c->d[1], "chunk", g_chunk);
     }
-    c->prog = v224hip_progressive_begin(c->d, c->d[1] ? 2 : 1, c->expected, d, VD_SHARE_WARM);
+    c->prog = v224hip_progressive_begin(c->d, c->d[1] ? 2 : 1, c->expected, d, VD_PROG_WARM);
     if (!c->prog) return -1;
   }
   return v224hip_progressive_feed(c->prog, s, n);

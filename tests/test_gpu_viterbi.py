@@ -651,6 +651,8 @@ def test_progressive_two_decoder_stream_equals_one_decoder(pkg, case, monkeypatc
     pieces = [int(x) for x in rng.integers(1, 3000, 200)] + [1, 2, 3]
     got, redone = _progressive(pkg, decs, syms, nbits, expected, delay, pieces)
     assert len(got) == nbits and np.array_equal(got, want)
+    got_min, redone_min = _progressive(pkg, decs, syms, nbits, expected, delay, pieces, warm=1)      # raised to 2 chunks
+    assert np.array_equal(got_min, want) and (case != "as_expected" or redone_min == 0)
     assert redone == (1 if case == "forced_redo" else redone)
     if case in ("as_expected", "longer_than_expected", "just_past_the_cut"):
         assert redone == 0
