@@ -118,12 +118,17 @@ extern "C" int v224hip_set_device(int dev) {
 // ------------------------------------------------------------------------------------------
 // kernels: init, simple ACS
 // ------------------------------------------------------------------------------------------
+// all metrics 1000 above the start state's (port.c:41-44); `start` = where that state sits in the buffer's order
 __global__ __launch_bounds__(256) void k_init(uint16_t *m, unsigned start, V224Dev *ds,
                                               uint32_t *rowmeta, int len) {
   unsigned t = blockIdx.x * 256 + threadIdx.x;            // 2^20 threads x 8 states
   uint4 v;
   const unsigned fill = (V224_BASE + 1000u) * 0x10001u;
   v.x = v.y = v.z = v.w = fill;
+  if (t == (start >> 3)) {
+    const unsigned one = (start & 1u) ? (V224_BASE << 16) | (V224_BASE + 1000u) : ((V224_BASE + 1000u) << 16) | V224_BASE;
+    switch ((start >> 1) & 3u) { case 0: v.x = one; break; case 1: v.y = one; break; case 2: v.z = one; break; default: v.w = one; }
+  }
   reinterpret_cast<uint4 *>(m)[t] = v;
   if (t == 0) {
     ds->blkmin[0][0] = V224_BASE; ds->nmin[0] = 1; ds->nmin[1] = 0;
@@ -131,7 +136,6 @@ __global__ __launch_bounds__(256) void k_init(uint16_t *m, unsigned start, V224D
   }
   (void)rowmeta; (void)len;
 }
-__global__ void k_init_start(uint16_t *m, unsigned start) { m[start] = (uint16_t)V224_BASE; }
 
 // wave64 minimum with DPP row operations (VALU only; __shfl_xor would be six ds_bpermute round trips)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
@@ -366,9 +370,9 @@ __global__ __launch_bounds__(64) void k_chainback_spec(const uint32_t *__restric
 // normally on the true path.  "Normally" is then checked: going down from the top, the state a piece was entered with
 // must equal the state the piece above (already known to be true) left with; a piece that fails is walked again from
 // the true state by wave 0 before the check goes on.  So a frame of merged paths costs (piece + warm-up)/6 memory
-// round trips instead of nbits/6 (1 024 bits: 43 instead of 171), and a frame of pure noise at worst ~1.3x the serial walk.
+// round trips instead of nbits/6 (1 024 bits: 32 instead of 171), and a frame of pure noise at worst ~1.3x the serial walk.
 #define CB_WAVES 16
-#define CB_WARM 192
+#define CB_WARM 128                          /* measured (scratch/cb_warm.py): 0-1 of 180 pieces walked again at Eb/N0 >= 2 dB, 13 % at 1 dB */
 #define CB_MAXBYTES 10240                     /* 81 920 bits: vtest224.c:30 caps frames at 80 000 */
 #define CB_MINBITS 512
 
@@ -401,7 +405,7 @@ __device__ __forceinline__ unsigned cb_walk(const uint32_t *__restrict__ rows, c
 
 __global__ __launch_bounds__(CB_WAVES * 64) void k_chainback_par(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowmeta,
                                                                  int len, unsigned nbits, unsigned endstate,
-                                                                 uint8_t *__restrict__ data, unsigned row0, unsigned *__restrict__ redone) {
+                                                                 uint8_t *__restrict__ data, unsigned row0, unsigned *__restrict__ redone, int cbwarm) {
   __shared__ unsigned s_in[CB_WAVES], s_out[CB_WAVES];
   __shared__ uint8_t s_data[CB_MAXBYTES];
   const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(CB_WAVES * 64) void k_chainback_par(const uint32_t 
   auto piece_hi = [&](unsigned k) { return k + 1 == CB_WAVES ? (long long)nbits : piece_lo(k + 1); };   // one past its last
   {
     const long long lo = piece_lo(w), hi = piece_hi(w);
-    long long top = hi + CB_WARM;
+    long long top = hi + cbwarm;
     unsigned st = 0;
     if (top >= (long long)nbits) { top = nbits; st = endstate & V224_SMASK; }                    // nothing to guess
     if (top > hi) st = cb_walk(rows, rowmeta, len, row0, top - 1, hi, st, nullptr, lane, lvl, cand);
@@ -721,9 +725,11 @@ static int init_enqueue(V224 *v, int starting_state, bool wait_tracebacks) {
   HIPCHK(hipSetDevice(v->dev));
   if (wait_tracebacks && v->st2 != v->st) HIPCHK(hipStreamSynchronize(v->st2));        // no traceback may still be reading
   v->cur = 0; v->dp = 0; v->nsteps = 0; v->pass = 0; v->min_valid = true;
-  v->layout = 0; v->fresh = true; v->start = (unsigned)starting_state & V224_SMASK;
-  k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], 0, v->ds, v->rowmeta, v->len);
-  k_init_start<<<1, 1, 0, v->st>>>(v->m[0], (unsigned)starting_state & V224_SMASK);
+  v->fresh = true; v->start = (unsigned)starting_state & V224_SMASK;
+  // one kernel, straight in the metric order the engine's first pass wants (a fresh buffer in the other order is a
+  // two-element patch away: ensure_layout)
+  v->layout = (v->engine == V224HIP_ENGINE_LDS15 && v->len >= 15) ? 1 : 0;
+  k_init<<<V224_NSTATES / 8 / 256, 256, 0, v->st>>>(v->m[0], v->layout ? l15_phys(v->start) : v->start, v->ds, v->rowmeta, v->len);
   HIPCHK(hipGetLastError());
   return 0;
 fail:
@@ -965,12 +971,13 @@ fail:
 
 // framed chainback on stream st: 16 verified pieces at once where the frame is long enough, else the serial walk
 static void launch_chainback(V224 *v, hipStream_t st, unsigned nbits, unsigned endstate, uint8_t *d_out, unsigned row0) {
-  static const int serial = getenv("V224HIP_SERIAL_CHAINBACK") ? atoi(getenv("V224HIP_SERIAL_CHAINBACK")) : 0;   // 1: one lane, 2: one wave
+  const int serial = env_int("V224HIP_SERIAL_CHAINBACK", 0);   // 1: one lane, 2: one wave (read per call: tests switch it)
   if (serial == 1 && row0 == 0) k_chainback<<<1, 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out);
   else if (serial || nbits < CB_MINBITS || nbits > 8u * CB_MAXBYTES)
     k_chainback_spec<<<1, 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out, row0);
   else
-    k_chainback_par<<<1, CB_WAVES * 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out, row0, (unsigned *)(v->dmisc + 96));
+    k_chainback_par<<<1, CB_WAVES * 64, 0, st>>>(v->rows, v->rowmeta, v->len, nbits, endstate, d_out, row0, (unsigned *)(v->dmisc + 96),
+                                                 env_int("V224HIP_CB_WARM", CB_WARM));
 }
 
 extern "C" int chainback_viterbi224(void *p, unsigned char *data, unsigned int nbits,
@@ -999,6 +1006,7 @@ fail:
 extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint8_t *syms, int nframes,
                                      int framebits, int startstate, unsigned int endstate, uint8_t *out) {
   uint8_t *d_syms = nullptr, *d_out = nullptr;       // = decoder 0's staging buffers
+  int rc = -1;
   if (!decoders || ndec <= 0 || nframes < 0 || framebits <= 0 || !syms || !out) {
     snprintf(g_err, sizeof g_err, "decode_frames: bad argument");
     return -1;
@@ -1027,7 +1035,9 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
       V224 *v = (V224 *)decoders[i];
       if (v->len < 2 * padbits || v->engine != v0->engine || v->st2 == v->st) dual = false;
     }
-    const int runbits = dual ? padbits : framebits;
+    bool pad = padbits != framebits;
+    for (int i = 0; i < ndec; i++) if (((V224 *)decoders[i])->len < padbits || ((V224 *)decoders[i])->engine != v0->engine) pad = false;
+    const int runbits = (dual || pad) ? padbits : framebits;
     const size_t stride = 2 * (size_t)runbits;
     // staging lives in decoder 0 (grow-only, kept between calls): no hipMalloc / hipFree per batch
     for (int i = 0; i < ndec; i++) { HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st)); HIPCHK(hipStreamSynchronize(((V224 *)decoders[i])->st2)); }
@@ -1053,7 +1063,7 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
         HIPCHK(hipStreamWaitEvent(v->st2, v->ev_acs[h], 0));
         launch_chainback(v, v->st2, (unsigned)framebits, endstate, d_out + outbytes * f, (unsigned)(h * padbits));
         HIPCHK(hipEventRecord(v->ev_tb[h], v->st2));
-      } else
+      } else if (!getenv("V224HIP_FRAMES_NO_TB"))          // (measurement hook: passes only)
         launch_chainback(v, v->st, (unsigned)framebits, endstate, d_out + outbytes * f, 0);
     }
     HIPCHK(hipGetLastError());
@@ -1066,10 +1076,10 @@ extern "C" int v224hip_decode_frames(void *const *decoders, int ndec, const uint
     HIPCHK(hipMemcpyAsync(out, d_out, outbytes * nframes, hipMemcpyDeviceToHost, v0->st));
     HIPCHK(hipStreamSynchronize(v0->st));
   }
-  return 0;
+  rc = 0;
 fail:
-  for (int i = 0; i < ndec; i++) if (decoders[i]) { (void)hipStreamSynchronize(((V224 *)decoders[i])->st); (void)hipStreamSynchronize(((V224 *)decoders[i])->st2); }
-  return -1;
+  if (rc != 0) for (int i = 0; i < ndec; i++) if (decoders[i]) { (void)hipStreamSynchronize(((V224 *)decoders[i])->st); (void)hipStreamSynchronize(((V224 *)decoders[i])->st2); }
+  return rc;
 }
 
 static int metric_extreme(V224 *v, int want_max, long long *out) {

@@ -271,6 +271,29 @@ def test_config1_framed_frames_vs_oracle(pkg, dist):
     o.close()
 
 
+@pytest.mark.parametrize("ndec", [2, 3])
+def test_decode_frames_large_batch(pkg, ndec, monkeypatch):
+    """A batch of a dozen frames per decoder (frames padded to whole 15-step passes, tracebacks in 16 pieces): the same
+    bytes with the one-wave traceback, and the oracle's for frames picked across the batch."""
+    framebits, nframes = 600, 12 * ndec + 1
+    frames = [orc.gen_coded_frame(7500 + f, framebits, 3.0, 24.0)[0] if f % 5 else orc.gen_uniform(7500 + f, 2 * framebits)
+              for f in range(nframes)]
+    syms = np.concatenate(frames)
+    decs = [pkg.Viterbi224(2 * 600) for _ in range(ndec)]
+    got = pkg.decode_frames(decs, syms, nframes, framebits, 0x819fbe, 0x155555)
+    monkeypatch.setenv("V224HIP_SERIAL_CHAINBACK", "2")
+    plain = pkg.decode_frames(decs, syms, nframes, framebits, 0x819fbe, 0x155555)
+    assert np.array_equal(got, plain)
+    o = orc.OracleV224(framebits, orc.FAST)
+    for f in (0, 1, ndec, nframes // 2, nframes - 1):
+        o.init(0x819fbe)
+        o.update(frames[f], framebits)
+        assert np.array_equal(got[f], o.chainback(framebits, 0x155555)), "frame %d" % f
+    o.close()
+    for d in decs:
+        d.close()
+
+
 @pytest.mark.parametrize("nbits", [511, 512, 519, 1024, 1031, 3000, 4099])
 def test_chainback_in_pieces_equals_serial_walk(pkg, nbits):
     """chainback_viterbi224 walks frames of >= 512 bits in 16 pieces at once, each verified against the piece above
