@@ -478,6 +478,16 @@ def main():
                                      "(measured for this VOP3P / VOP2 mix, profiles/r01_valu_rate.txt) / (launch time x %.1f GHz); "
                                      "the SURVEY 8(d) algorithmic bytes exceed what is physically moved (algorithmic_x_peak)"
                                      % (cyc, CLOCK_GHZ)})
+                if single and single.get("split_avg_launch_ms"):
+                    # the headline mode: two decoders' launches side by side; decoder 0's launch period then covers one
+                    # launch of EACH decoder
+                    tp = single["split_avg_launch_ms"] * 1e-3
+                    roof["two_decoders"] = {"launch_pair_ms": single["split_avg_launch_ms"],
+                                            "achieved": round(2 * valu * WAVES_PER_LAUNCH / tp / 1e9, 1),
+                                            "frac": round(2 * valu * WAVES_PER_LAUNCH / tp / 1e9 / peak, 4),
+                                            "hbm_physical_frac": round(2 * traffic / tp / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                                            "what": "the same fractions during the timed split steps (HIP events on decoder 0's "
+                                                    "stream while decoder 1's launches run beside it)"}
             elif traffic:
                 roof.update({"achieved": roof["hbm_physical_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": roof["hbm_physical_frac"]})
