@@ -208,7 +208,7 @@ def frames_record(pkg, synth, nframes=50, framebits=1000):
                    "out (H2D of the symbols and D2H of the bytes inside the time)" % (nframes, framebits)}
     out = None
     for nd in (2, 3):
-        pkg.decode_frames(decs[:nd], syms, min(nframes, 8), framebits)
+        pkg.decode_frames(decs[:nd], syms, nframes, framebits)          # warm-up at full size: the staging buffers are grown once
         t0 = time.perf_counter()
         got = pkg.decode_frames(decs[:nd], syms, nframes, framebits)
         dt = time.perf_counter() - t0

@@ -26,13 +26,13 @@ print("2 decoders x 4 frames: %.3f ms per frame" % ((t1-t0)*1e3/8))
 d3 = pkg.Viterbi224(nb)
 frames = np.tile(syms[:2 * nb], 32)
 for decs in ([d], [d, d2], [d, d2, d3]):
-    pkg.decode_frames(decs, frames, 4, nb)
+    pkg.decode_frames(decs, frames, 32, nb)      # (same size as the timed call: staging buffers grow once)
     t0 = time.perf_counter(); out = pkg.decode_frames(decs, frames, 32, nb); t1 = time.perf_counter()
     print("decode_frames, %d decoder(s): %.3f ms per 1024-bit frame = %.3f Msymbols/s" % (len(decs), (t1 - t0) * 1e3 / 32, 32 * 2 * nb / (t1 - t0) / 1e6))
 # rings of two padded frames: tracebacks under the next frame's passes, no remainder pass
 big = [pkg.Viterbi224(2 * 1035) for _ in range(3)]
 for decs in (big[:1], big[:2], big[:3]):
-    pkg.decode_frames(decs, frames, 4, nb)
+    pkg.decode_frames(decs, frames, 32, nb)      # (same size as the timed call: staging buffers grow once)
     t0 = time.perf_counter(); out2 = pkg.decode_frames(decs, frames, 32, nb); t1 = time.perf_counter()
     assert np.array_equal(out2, out)
     print("decode_frames, %d decoder(s) with 2 x 1035 rows: %.3f ms per 1024-bit frame = %.3f Msymbols/s" % (len(decs), (t1 - t0) * 1e3 / 32, 32 * 2 * nb / (t1 - t0) / 1e6))
