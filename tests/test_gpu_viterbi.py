@@ -684,3 +684,34 @@ def test_progressive_two_decoder_stream_equals_one_decoder(pkg, case, monkeypatc
     assert np.array_equal(got2, want[:min(nbits, 20_000)])
     for d in decs + [one]:
         d.close()
+
+
+def test_progressive_api_refuses_bad_arguments(pkg):
+    """Error behaviour of v224hip_progressive_*: NULL handle / decoders, mismatched chunk sizes, a ring too short for the
+    delay, an output buffer too small -- -1 / NULL with a message, nothing left behind, decoders usable afterwards."""
+    import ctypes as C
+    L = pkg.v224_lib()
+    u8p = C.POINTER(C.c_uint8)
+    a, b = pkg.Viterbi224(200 + 2040), pkg.Viterbi224(200 + 2040)
+    b.set_option("chunk", 1020)                                    # a keeps 2040
+    hs = (C.c_void_p * 2)(a.h, b.h)
+    assert not L.v224hip_progressive_begin(hs, 2, 50_000, 200, 3060) and b"chunk" in L.v224hip_last_error()
+    assert not L.v224hip_progressive_begin(None, 2, 50_000, 200, 3060)
+    assert not L.v224hip_progressive_begin(hs, 1, 50_000, 5000, 3060) and b"short ring" in L.v224hip_last_error()
+    assert L.v224hip_progressive_feed(None, None, 0) == -1
+    assert L.v224hip_progressive_end(None, None, 0, None, None) == -1
+    L.v224hip_progressive_abort(None)
+    b.set_option("chunk", 2040)
+    syms, _ = orc.gen_coded_stream(9850, 9000, 3.0, 24.0, 0)
+    h = L.v224hip_progressive_begin(hs, 2, 9000, 200, 3060)
+    assert h
+    assert L.v224hip_progressive_feed(h, syms.ctypes.data_as(u8p), 9000) == 0
+    small = np.zeros(100, dtype=np.uint8)
+    n, r = C.c_longlong(7), C.c_int(7)
+    assert L.v224hip_progressive_end(h, small.ctypes.data_as(u8p), 100, C.byref(n), C.byref(r)) == -1      # handle is gone now
+    assert n.value == 0 and b"too small" in L.v224hip_last_error()
+    a.init(0)
+    want = a.stream_decode(syms, 200)
+    got, _ = _progressive(pkg, [a, b], syms, 9000, 9000, 200, [4000, 5000])
+    assert np.array_equal(got, want)
+    a.close(); b.close()
