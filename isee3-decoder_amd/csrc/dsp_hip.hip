@@ -565,6 +565,7 @@ struct Pmd {
   const int16_t *cur_iq; int cur_flip;   // the block pmd_load announced (device memory): read by the FFT's first pass,
                                          // by the spin-down sum and by the output kernel -- no double-precision copy of it exists
   void *d_red; size_t red_cap;           // reduction scratch
+  void *d_peakpart; size_t peakpart_cap; // one peak record per workgroup of the last FFT pass
   int16_t *d_out16; double *d_pre;
   int have_lo;
   Pin pin_hdr;                           // peak record @0, spin-down sum @128, variance sum @144: written by the kernels
@@ -721,11 +722,17 @@ constexpr int lg2c(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 #define SRC_IQ 1
 #define SRC_REAL16 2
 #define SRC_CONJPROD 3
-template <int LG, int SRC, bool FIRST>
+struct PeakRec { double e; int idx; int pad; };
+__device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) {
+  return e > be || (e == be && i > bi);     // ">=" while scanning upward == last maximum wins
+}
+// PEAK (the last pass of pmdemod's transform): the |X|^2 arg-max of pmdemod.c:255-279 over bins [pfirst, plast) rides on
+// the pass that produces the bins -- one PeakRec per workgroup -- instead of reading the 16 N bytes of spectrum again
+template <int LG, int SRC, bool FIRST, bool PEAK = false>
 __global__ __launch_bounds__(FT * (PassShape<LG>::R1 > PassShape<LG>::R2 ? PassShape<LG>::R1 : PassShape<LG>::R2))
 void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip,
                 double2 *__restrict__ y, const double2 *__restrict__ twA, const double2 *__restrict__ twB,
-                const double2 *__restrict__ twR, int N, int s) {
+                const double2 *__restrict__ twR, int N, int s, int pfirst = 0, int plast = 0, PeakRec *__restrict__ ppart = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2;
   extern __shared__ double2 Z[];                          // [R2][R1][FT]
   const int c = threadIdx.x & (FT - 1), r = threadIdx.x >> 4;
@@ -749,6 +756,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     }
   }
   __syncthreads();
+  double be = -1.0; int bi = -1;
   if (r < R1) {                                           // ---- step 2, thread (c, k1 = r)
     double2 u[R2];
 #pragma unroll
@@ -778,6 +786,27 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
       }
       if (walk) wk = cmul(wk, wstep);
       out[(size_t)k * s] = val;
+      if constexpr (PEAK) {
+        const int i = q + R * ps + k * s;                   // the bin this value is (the last pass: N fits an int)
+        const double e = val.x * val.x + val.y * val.y;
+        if (i >= pfirst && i < plast && peak_better(e, i, be, bi)) { be = e; bi = i; }
+      }
+    }
+  }
+  if constexpr (PEAK) {
+    constexpr int TH = FT * (R1 > R2 ? R1 : R2), NW = (TH + 63) / 64;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double oe = __shfl_xor(be, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (peak_better(oe, oi, be, bi)) { be = oe; bi = oi; }
+    }
+    __syncthreads();                                        // every thread has read its part of Z
+    PeakRec *ws = reinterpret_cast<PeakRec *>(Z);
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6].e = be; ws[threadIdx.x >> 6].idx = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < NW; w++) if (peak_better(ws[w].e, ws[w].idx, be, bi)) { be = ws[w].e; bi = ws[w].idx; }
+      ppart[blockIdx.x].e = be; ppart[blockIdx.x].idx = bi;
     }
   }
 }
@@ -790,10 +819,6 @@ __global__ __launch_bounds__(256) void k_twiddles2(double2 *twA, double2 *twB, d
   if (i < 256) { sincospi(-2.0 * (double)i / 256.0, &sn, &cs); twR[i] = make_double2(cs, sn); }
 }
 
-struct PeakRec { double e; int idx; int pad; };
-__device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) {
-  return e > be || (e == be && i > bi);     // ">=" while scanning upward == last maximum wins
-}
 __global__ __launch_bounds__(256) void k_peak_partial(const double2 *__restrict__ spec, int first, int last,
                                                       PeakRec *__restrict__ part) {
   double be = -1.0; int bi = -1;
@@ -910,39 +935,48 @@ __global__ __launch_bounds__(256) void k_rotate(const short2 *__restrict__ iq, c
 struct FftCtx { int N, logN; const double2 *twA, *twB, *twR; hipStream_t st; };
 struct FftSrc { const double2 *x; const void *i16; const double2 *aux; int iparam; };   // see SRC_*: (x) | (iq, lo, flip) | (samples, -, nvalid) | (x, v)
 
-template <int LG, int SRC, bool FIRST>
-static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s) {
+struct PeakAsk { int first, last; PeakRec *part; int nparts; };     // nparts: set by the launch (one per workgroup)
+template <int LG, int SRC, bool FIRST, bool PEAK = false>
+static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FT * (R1 > R2 ? R1 : R2);
   const size_t lds = sizeof(double2) * R * FT;
   static bool attr_set = false;                      // 64 KiB of dynamic LDS at R = 256
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST, PEAK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set = true;
   }
-  k_fft_pass<LG, SRC, FIRST><<<c.N / R / FT, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
+  if constexpr (PEAK) {
+    pk->nparts = c.N / R / FT;
+    k_fft_pass<LG, SRC, FIRST, true><<<c.N / R / FT, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s,
+                                                                      pk->first, pk->last, pk->part);
+  } else
+    k_fft_pass<LG, SRC, FIRST, false><<<c.N / R / FT, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
   return 0;
 }
-template <int SRC, bool FIRST>
-static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, double2 *dst, int s) {
+template <int SRC, bool FIRST, bool PEAK = false>
+static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
   switch (lg) {
-  case 5: return launch_pass<5, SRC, FIRST>(c, in, dst, s);
-  case 6: return launch_pass<6, SRC, FIRST>(c, in, dst, s);
-  case 7: return launch_pass<7, SRC, FIRST>(c, in, dst, s);
-  case 8: return launch_pass<8, SRC, FIRST>(c, in, dst, s);
+  case 5: return launch_pass<5, SRC, FIRST, PEAK>(c, in, dst, s, pk);
+  case 6: return launch_pass<6, SRC, FIRST, PEAK>(c, in, dst, s, pk);
+  case 7: return launch_pass<7, SRC, FIRST, PEAK>(c, in, dst, s, pk);
+  case 8: return launch_pass<8, SRC, FIRST, PEAK>(c, in, dst, s, pk);
   }
   return -1;
 }
 // forward unnormalised transform of N = 2^logN >= 2^12 points: ceil(logN / 8) LDS-staged passes of 5..8 levels each, the
 // first one reading `in` in the form SRC; ping-pong between out and tmp so that the last pass lands in `out`
+// (pk: the last pass -- never the first: N >= 2^12 takes two -- also leaves per-workgroup peak records)
 template <int SRC>
-static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 *tmp) {
+static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 *tmp, PeakAsk *pk = nullptr) {
   const int npass = (c.logN + 7) / 8, base = c.logN / npass, extra = c.logN % npass;
   FftSrc cur = in;
   int s = 1;
+  if (pk) pk->nparts = 0;
   for (int i = 0; i < npass; i++) {
     const int lg = base + (i < extra ? 1 : 0);
     double2 *dst = ((npass - 1 - i) & 1) == 0 ? out : tmp;
-    if ((i == 0 ? launch_pass_lg<SRC, true>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false>(c, lg, cur, dst, s)) != 0) return -1;
+    if (pk && i == npass - 1 && i > 0) { if (launch_pass_lg<SRC_C2, false, true>(c, lg, cur, dst, s, pk) != 0) return -1; }
+    else if ((i == 0 ? launch_pass_lg<SRC, true>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false>(c, lg, cur, dst, s)) != 0) return -1;
     cur = FftSrc{dst, nullptr, nullptr, 0}; s <<= lg;
   }
   return 0;
@@ -998,7 +1032,7 @@ extern "C" void pmd_destroy(void *p) {
   (void)hipStreamSynchronize(h->st); if (h->st && h->own_st) (void)hipStreamDestroy(h->st);
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
-  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red); (void)hipFree(h->d_peakpart);
   pin_free(&h->pin_hdr);
   free(h);
 }
@@ -1043,11 +1077,14 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
   if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: no block loaded"); return -1; }
   CHK(hipSetDevice(h->dev));
   {
+    PeakAsk ask{firstbin, lastbin, nullptr, 0};
     if (!h->buf) {
-      // LDS-staged passes, the first one straight from the int16 block
+      // LDS-staged passes, the first one straight from the int16 block, the last one leaving the peak records
       const FftCtx c{h->N, h->logN, h->twA, h->twB, h->twR, h->st};
       const FftSrc in{nullptr, h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip};
-      if (fft_forward<SRC_IQ>(c, in, h->spec, h->tmp) != 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: FFT launch failed"); return -1; }
+      const bool ride = !getenv("ISEE3DSP_PEAK_SEPARATE") && grow(&h->d_peakpart, &h->peakpart_cap, sizeof(PeakRec) * (size_t)(h->N / 32 / FT)) == 0;
+      ask.part = (PeakRec *)h->d_peakpart;
+      if (fft_forward<SRC_IQ>(c, in, h->spec, h->tmp, ride ? &ask : nullptr) != 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: FFT launch failed"); return -1; }
     } else {
       // stages ping-pong so that the last one lands in spec; buf is never written.  Radix plan: the
       // small remainder radix first (its short output runs matter least while s is tiny), then radix 16.
@@ -1074,7 +1111,8 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
     int nb = (lastbin - firstbin + 255) / 256;
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     if (nb < 1) nb = 1;
-    k_peak_partial<<<nb, 256, 0, h->st>>>(h->spec, firstbin, lastbin, part);
+    if (ask.nparts > 0) { part = ask.part; nb = ask.nparts; }                                  // the last FFT pass has done it
+    else k_peak_partial<<<nb, 256, 0, h->st>>>(h->spec, firstbin, lastbin, part);
     k_peak_final<<<1, 256, 0, h->st>>>(part, nb, h->spec, h->N, (pmd_peak *)h->pin_hdr.d);      // straight into mapped host memory
     CHK(hipGetLastError());
     CHK(hipStreamSynchronize(h->st));
