@@ -1376,28 +1376,31 @@ struct V224Prog {
   long long cap;                           // bits the device buffers hold
   long long avail, a_pos, b_pos;           // bits uploaded; next bit of decoder 0 / of decoder 1 (b_pos starts at start1 - warm)
   bool b_started, a_snapped, b_snapped;
-  // how far decoder 0 has really got (not just been told to go): events recorded behind its calls, polled oldest first
+  // how far each decoder has really got (not just been told to go): events recorded behind its calls, polled oldest first
   enum { NEV = 32 };
-  hipEvent_t ev[NEV]; long long ev_pos[NEV]; int ev_head, ev_count;
-  long long a_done;
+  struct Track { hipEvent_t ev[NEV]; long long pos[NEV]; int head, count; long long done; } tr[2];
   double t_begin, t_cut, a_done_at_cut, avail_at_cut;      // V224HIP_VERBOSE report
 };
 static double prog_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
-#define PROG_LOOK 6        /* chunks decoder 0 is told ahead of what it has finished while the cut is still open */
+#define PROG_LOOK_PRE 6    /* chunks decoder 0 is told ahead of what it has finished while the cut is still open */
+#define PROG_LOOK 24       /* ... and either decoder afterwards: feed() hands out work for some tens of ms, never the whole backlog */
+#define PROG_SLAB 8        /* chunks per call when both decoders have a backlog: their launches must interleave in the queues */
 
-static void prog_poll(V224Prog *g) {
-  while (g->ev_count > 0 && hipEventQuery(g->ev[g->ev_head]) == hipSuccess) {
-    g->a_done = g->ev_pos[g->ev_head];
-    g->ev_head = (g->ev_head + 1) % V224Prog::NEV; g->ev_count--;
+static void prog_poll(V224Prog *g, int j) {
+  V224Prog::Track &t = g->tr[j];
+  while (t.count > 0 && hipEventQuery(t.ev[t.head]) == hipSuccess) {
+    t.done = t.pos[t.head];
+    t.head = (t.head + 1) % V224Prog::NEV; t.count--;
   }
   (void)hipGetLastError();                 // hipErrorNotReady is not an error here
 }
-static void prog_mark(V224Prog *g) {
-  if (g->ev_count >= V224Prog::NEV) return;                   // all in flight: the next poll will see an older one first
-  const int i = (g->ev_head + g->ev_count) % V224Prog::NEV;
-  if (!g->ev[i] && hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess) { g->ev[i] = nullptr; return; }
-  if (hipEventRecord(g->ev[i], g->d[0]->st) != hipSuccess) return;
-  g->ev_pos[i] = g->a_pos; g->ev_count++;
+static void prog_mark(V224Prog *g, int j, long long pos) {
+  V224Prog::Track &t = g->tr[j];
+  if (t.count >= V224Prog::NEV) return;                       // all in flight: the next poll will see an older one first
+  const int i = (t.head + t.count) % V224Prog::NEV;
+  if (!t.ev[i] && hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming) != hipSuccess) { t.ev[i] = nullptr; return; }
+  if (hipEventRecord(t.ev[i], g->d[j]->st) != hipSuccess) return;
+  t.pos[i] = pos; t.count++;
 }
 
 static int prog_grow(V224Prog *g, long long need) {
@@ -1424,78 +1427,84 @@ fail:
 }
 
 // enqueue what the symbols known so far allow.  Unless `final`, a decoder advances in whole chunks only (a ragged call
-// would cost remainder passes and a switch of the metric order in the middle of the stream).
+// would cost remainder passes and a switch of the metric order in the middle of the stream), and is told at most PROG_LOOK
+// chunks ahead of what it has finished: feed() returns at once, and the launches of the two decoders sit next to each
+// other in the device queues (a decoder handed its whole backlog in one go keeps the host inside that call until the
+// backlog has drained, and the other decoder idle meanwhile).
 //
 // Where the cut goes is decided when decoder 1 can start, not before: if decoder 0 has finished a_done bits by then
 // and both run at the same (pair) rate from then on, they finish together when x - a_done = expected - x + warm, i.e.
 // x = (expected + warm + a_done) / 2 -- later than the middle by half of what decoder 0 managed alone.  Symbols that
 // arrive no faster than one decoder decodes push x to the end (no second part: nothing to gain); symbols that are all
-// there at once give the even split of split_core.  Until the cut is fixed decoder 0 is only told PROG_LOOK chunks ahead
-// of what it has finished, so that its snapshot at x - check can still be placed.
+// there at once give the even split of split_core.  Until the cut is fixed decoder 0 is only told PROG_LOOK_PRE chunks
+// ahead of what it has finished, so that its snapshot at x - check can still be placed.
+
+// one step of decoder j: at most PROG_SLAB chunks.  > 0: something was enqueued (or a snapshot taken), 0: nothing to do now
+static int prog_step(V224Prog *g, int j, bool final) {
+  const long long q = g->chunk;
+  V224 *v = g->d[j];
+  long long &pos = j == 0 ? g->a_pos : g->b_pos;
+  bool &snapped = j == 0 ? g->a_snapped : g->b_snapped;
+  long long lim = g->avail;
+  uint8_t *out = g->d_out + pos;
+  if (j == 0) {
+    if (g->start1 >= 0) {
+      if (lim > g->start1) lim = g->start1;
+      if (!snapped && lim > g->start1 - g->check) lim = g->start1 - g->check;
+    }
+  } else {
+    if (g->start1 < 0 || (final && g->avail <= g->start1) || g->avail <= pos) return 0;     // no second part (planned, or reached)
+    if (!g->b_started) {
+      if (g->avail - pos < q && !final) return 0;
+      if (init_viterbi224(v, 0) != 0) return -1;
+      g->b_started = true;
+    }
+    if (!snapped) { if (lim > g->start1 - g->check) lim = g->start1 - g->check; }
+    else if (pos < g->start1 && lim > g->start1) lim = g->start1;
+    if (pos < g->start1) out = v->warmout + (pos - (g->start1 - g->warm));                    // warm-up and seam window: not output
+  }
+  if (!final) {
+    const long long look = (j == 0 && g->start1 < 0 && g->can_split) ? PROG_LOOK_PRE : PROG_LOOK;
+    if (lim > (g->tr[j].done + look * q) / q * q) lim = (g->tr[j].done + look * q) / q * q;
+  }
+  long long n = lim - pos;
+  if (n > PROG_SLAB * q) n = PROG_SLAB * q;
+  if (!(final && pos + n == g->avail)) n = n / q * q;          // ragged only at the very end of the stream
+  if (n > 0) {
+    if (v224hip_stream_decode_dev(v, g->d_syms + 2 * pos, (int)n, g->delay, out) != 0) return -1;
+    pos += n;
+    prog_mark(g, j, pos);
+  }
+  if (g->start1 >= 0 && !snapped && pos == g->start1 - g->check && (j == 0 || g->b_started)) {
+    if (prog_snapshot(v, j) != 0) return -1;
+    snapped = true;
+    return 1;
+  }
+  return n > 0 ? 1 : 0;
+}
+
 static int prog_advance(V224Prog *g, bool final) {
   const long long q = g->chunk;
-  prog_poll(g);
+  for (int j = 0; j < g->ndec; j++) prog_poll(g, j);
   if (g->can_split && g->start1 < 0) {
     if (final) g->can_split = false;                           // everything is known and decoder 1 never got going
     else {
-      long long x = (g->expected + g->warm + g->a_done) / 2 / q * q;
-      if (x - g->check < g->a_pos) x = (g->a_pos + g->check + q - 1) / q * q;      // (cannot happen with PROG_LOOK < warm / chunk)
+      const long long a_done = g->tr[0].done;
+      long long x = (g->expected + g->warm + a_done) / 2 / q * q;
+      if (x - g->check < g->a_pos) x = (g->a_pos + g->check + q - 1) / q * q;      // (cannot happen with PROG_LOOK_PRE < warm / chunk)
       if (x + 2 * q > g->expected) g->can_split = false;       // what would be left for decoder 1 is not worth a warm-up
       else if (g->avail >= x - g->warm + q && x - g->warm >= 0) {
-        g->start1 = x; g->b_pos = x - g->warm;
-        g->t_cut = prog_now(); g->a_done_at_cut = (double)g->a_done; g->avail_at_cut = (double)g->avail;
+        g->start1 = x; g->b_pos = x - g->warm; g->tr[1].done = g->b_pos;
+        g->t_cut = prog_now(); g->a_done_at_cut = (double)a_done; g->avail_at_cut = (double)g->avail;
       }
     }
   }
-  // decoder 0: [0, start1) -- or everything when there is no second part -- with its snapshot at start1 - check
-  for (;;) {
-    long long lim = g->avail;
-    if (g->start1 >= 0) {
-      if (lim > g->start1) lim = g->start1;
-      if (!g->a_snapped && lim > g->start1 - g->check) lim = g->start1 - g->check;
-    } else if (g->can_split && lim > g->a_done + PROG_LOOK * q) lim = (g->a_done + PROG_LOOK * q) / q * q;
-    long long n = lim - g->a_pos;
-    if (!final || lim < g->avail) n = n / q * q;               // (the planned boundaries are chunk multiples anyway)
-    if (n > 0) {
-      if (n > 0x40000000) n = 0x40000000 / q * q;
-      if (v224hip_stream_decode_dev(g->d[0], g->d_syms + 2 * g->a_pos, (int)n, g->delay, g->d_out + g->a_pos) != 0) return -1;
-      g->a_pos += n;
-      prog_mark(g);
-    }
-    if (g->start1 >= 0 && !g->a_snapped && g->a_pos == g->start1 - g->check) {
-      if (prog_snapshot(g->d[0], 0) != 0) return -1;
-      g->a_snapped = true;
-      continue;
-    }
-    if (n <= 0) break;
-  }
-  if (g->start1 < 0 || (final && g->avail <= g->start1)) return 0;       // no second part (planned, or reached)
-  // decoder 1: fresh start at start1 - warm, snapshot at start1 - check, then its part to the end
-  for (;;) {
-    if (g->avail <= g->b_pos) break;
-    if (!g->b_started) {
-      if (g->avail - g->b_pos < q && !final) break;
-      if (init_viterbi224(g->d[1], 0) != 0) return -1;
-      g->b_started = true;
-    }
-    long long lim = g->avail;
-    uint8_t *out;
-    if (!g->b_snapped) { if (lim > g->start1 - g->check) lim = g->start1 - g->check; out = g->d[1]->warmout + (g->b_pos - (g->start1 - g->warm)); }
-    else if (g->b_pos < g->start1) { if (lim > g->start1) lim = g->start1; out = g->d[1]->warmout + (g->b_pos - (g->start1 - g->warm)); }
-    else out = g->d_out + g->b_pos;
-    long long n = lim - g->b_pos;
-    if (!final || lim < g->avail) n = n / q * q;
-    if (n > 0) {
-      if (n > 0x40000000) n = 0x40000000 / q * q;
-      if (v224hip_stream_decode_dev(g->d[1], g->d_syms + 2 * g->b_pos, (int)n, g->delay, out) != 0) return -1;
-      g->b_pos += n;
-    }
-    if (!g->b_snapped && g->b_pos == g->start1 - g->check) {
-      if (prog_snapshot(g->d[1], 1) != 0) return -1;
-      g->b_snapped = true;
-      continue;
-    }
-    if (n <= 0) break;
+  for (;;) {                                                   // slab by slab, the two decoders in turn
+    const int ra = prog_step(g, 0, final);
+    if (ra < 0) return -1;
+    const int rb = g->ndec > 1 ? prog_step(g, 1, final) : 0;
+    if (rb < 0) return -1;
+    if (ra == 0 && rb == 0) break;
   }
   return 0;
 }
@@ -1504,7 +1513,7 @@ extern "C" void v224hip_progressive_abort(void *h) {
   V224Prog *g = (V224Prog *)h;
   if (!g) return;
   for (int j = 0; j < g->ndec; j++) if (g->d[j]) (void)hipStreamSynchronize(g->d[j]->st);
-  for (int i = 0; i < V224Prog::NEV; i++) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+  for (int j = 0; j < 2; j++) for (int i = 0; i < V224Prog::NEV; i++) if (g->tr[j].ev[i]) (void)hipEventDestroy(g->tr[j].ev[i]);
   (void)hipFree(g->d_syms); (void)hipFree(g->d_out);
   delete g;
 }
@@ -1584,8 +1593,8 @@ extern "C" int v224hip_progressive_end(void *h, uint8_t *out, long long cap, lon
   HIPCHK(hipSetDevice(g->d[0]->dev));
   {
     const double t_end = prog_now();
-    prog_poll(g);
-    const long long a_done_end = g->a_done;
+    prog_poll(g, 0);
+    const long long a_done_end = g->tr[0].done;
     if (prog_advance(g, true) != 0) goto done;
     if (getenv("V224HIP_VERBOSE")) {
       for (int j = 0; j < g->ndec; j++) (void)hipStreamSynchronize(g->d[j]->st);
