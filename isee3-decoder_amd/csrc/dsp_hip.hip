@@ -340,11 +340,19 @@ __global__ __launch_bounds__(256) void k_demod(const long long *__restrict__ P, 
     out[i] = (unsigned char)scaled;
   }
 }
-__global__ void k_seq_energy(const long long *__restrict__ symv, int nsymbols, double *energy) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// the reference's own order of additions (symdemod.c:297,325: energy += (double)(sym * sym), symbol by symbol): the squares
+// are formed by the whole block (independent loads), one thread then adds them in order out of LDS -- the same values in
+// the same order as the one-thread loop this replaces (90 us of dependent global loads at 1 024 symbols)
+__global__ __launch_bounds__(256) void k_seq_energy(const long long *__restrict__ symv, int nsymbols, double *energy) {
+  __shared__ double sq[1024];
   double e = 0;
-  for (int i = 0; i < nsymbols; i++) e += (double)(symv[i] * symv[i]);
-  *energy = e;
+  for (int base = 0; base < nsymbols; base += 1024) {
+    for (int i = threadIdx.x; i < 1024 && base + i < nsymbols; i += 256) sq[i] = (double)(symv[base + i] * symv[base + i]);
+    __syncthreads();
+    if (threadIdx.x == 0) for (int i = 0; i < 1024 && base + i < nsymbols; i++) e += sq[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *energy = e;
 }
 // exact-integer form of the same sum by one block (see k_timesearch_part); *inexact != 0 => rerun k_seq_energy
 __global__ __launch_bounds__(256) void k_par_energy(const long long *__restrict__ symv, int nsymbols, double *energy,
@@ -541,7 +549,7 @@ extern "C" int symd_demod(void *p, const int *edges, int symbolclocks, int nsymb
     CHK(hipStreamSynchronize(h->st));
     if (energy_sum) {
       if (*(volatile unsigned *)((char *)h->pin_hdr.h + 8) || getenv("ISEE3DSP_SEQUENTIAL")) {
-        k_seq_energy<<<1, 64, 0, h->st>>>((const long long *)h->d_sym, nsymbols, d_esum);
+        k_seq_energy<<<1, 256, 0, h->st>>>((const long long *)h->d_sym, nsymbols, d_esum);
         CHK(hipStreamSynchronize(h->st));
       }
       *energy_sum = *(volatile double *)((char *)h->pin_hdr.h + 16);
