@@ -461,18 +461,16 @@ static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   /* how the Viterbi stage takes its symbols.  "progressive": one stream, fed as it arrives, second decoder joining at a
    * cut placed from the expected number of bits (v224hip_progressive_*).  "block": block by block as the reference does,
    * long blocks shared once the front end has finished (bits leave as they are decoded: the form for pipes).  "whole":
-   * wait for all symbols, then split (ISEE3_CHAIN_WHOLE=1; measured 72 vs 57 ms in round 1).  Default: progressive when
-   * the capture's length is known and the Viterbi decoder is what the run will wait for -- one decoder's time for the
-   * expected bits (1.18 us each) against the front end's (10 Gsamples/s + 0.3 ms per pmdemod block, both measured on
-   * MI355X); where the front end is the slower part (10 MS/s captures) one decoder keeps up with the symbols, a second one
-   * has nothing to gain, and block mode has the shorter tail (it never waits for a whole chunk). */
+   * wait for all symbols, then split (ISEE3_CHAIN_WHOLE=1; measured 72 vs 57 ms in round 1).  Default: progressive whenever
+   * the capture's length is known.  Where the Viterbi decoder is the slower part (250 kS/s) the second decoder joins; where
+   * the front end is (10 MS/s) one decoder keeps up with the symbols and the cut is never placed -- and that one decoder
+   * still does better than block mode (48 s of 10 MS/s: 40.2 against 45.8 ms): it advances in whole chunks, asynchronously,
+   * where a block of whatever the pipe held costs remainder passes, two switches of the metric order and a wait. */
   {
     const char *m = getenv("ISEE3_CHAIN_MODE");
     const double secs = src->iq ? (double)src->nsamples / co->samprate : 0;
-    const double nblocks = co->binsize > 0 ? secs * co->binsize : 0;          /* one block = 1 / binsize seconds (pmdemod.c:129-131) */
-    const double front_ms = (double)src->nsamples / 1e7 + 0.3 * nblocks;
     va.expected_bits = (long long)(secs * sa.o.symrate / 2);
-    va.progressive = m ? !strcmp(m, "progressive") : (va.expected_bits >= 4 * VD_SHARE_WARM && 1.18e-3 * (double)va.expected_bits > front_ms);
+    va.progressive = m ? !strcmp(m, "progressive") : va.expected_bits > 0;
     va.o.whole_input = va.progressive || (m && !strcmp(m, "whole")) || (getenv("ISEE3_CHAIN_WHOLE") && atoi(getenv("ISEE3_CHAIN_WHOLE")));
   }
   pa.o.quiet = sa.o.quiet = va.o.quiet = !co->verbose;
