@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-OUT=gpurun_out/r02bm; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/r02br; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x > $OUT/gpu_tests.log 2>&1; rc=$?; tail -5 $OUT/gpu_tests.log
 [ $rc -ne 0 ] && exit 1
 timeout -k 10 400 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { tail -20 $OUT/bench_default.err; exit 1; }
