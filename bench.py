@@ -59,18 +59,48 @@ def _orc():
     return orc
 
 
-def cpu_baseline(nbits_sample):
-    """Reference SSE2 decoder on one host core (falls back to the oracle port restatement)."""
-    orc = _orc()
-    rng = np.random.default_rng(1)
-    syms = rng.integers(0, 256, 2 * nbits_sample, dtype=np.uint8)
-    if orc.have_ref():
-        d = orc.RefV224(256, "sse2")
-        kind, what = "reference", "viterbi224_sse2.c (oracle/_ref), update_viterbi224_blk"
-    else:
-        os.environ["OMP_NUM_THREADS"] = "1"
-        d = orc.OracleV224(256, orc.FAST)
-        kind, what = "port", "oracle FAST engine (port semantics, SSE2), 1 thread"
+def host_info():
+    """Where the CPU baselines ran: CPU model, logical CPUs of the box / of this process, and how the reference objects
+    under oracle/_ref were compiled (oracle/Makefile writes BUILD_FLAGS.txt beside them)."""
+    model, flags = "unknown", set()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    info = {"cpu_model": model, "nproc": os.cpu_count(), "nproc_allowed": len(os.sched_getaffinity(0)),
+            "avx2": "avx2" in flags}
+    bf = os.path.join(ROOT, "oracle", "_ref", "BUILD_FLAGS.txt")
+    if os.path.exists(bf):
+        info["ref_build"] = dict(l.strip().split(": ", 1) for l in open(bf) if ": " in l)
+    return info
+
+
+class pinned_to_one_core:
+    """The CPU legs run on ONE core: the process is pinned (sched_setaffinity, no taskset hop) to the first core it is
+    allowed on for the duration of the leg."""
+
+    def __enter__(self):
+        self.before = os.sched_getaffinity(0)
+        self.core = min(self.before)
+        try:
+            os.sched_setaffinity(0, {self.core})
+            self.ok = True
+        except OSError:
+            self.ok = False
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            os.sched_setaffinity(0, self.before)
+        except OSError:
+            pass
+
+
+def _time_ref_update(d, syms, nbits_sample):
     d.init(0)
     d.update(syms[:512], 256)                     # touch memory
     d.init(0)
@@ -80,20 +110,54 @@ def cpu_baseline(nbits_sample):
         n = min(256, nbits_sample - done)
         d.update(syms[2 * done:2 * (done + n)], n)
         done += n
-    dt = time.perf_counter() - t0
-    d.close()
-    res = {"value": round(2 * nbits_sample / dt / 1e6, 6), "unit": "Msymbols/s", "cores": 1, "kind": kind,
-           "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nbits_sample, what, dt)}
-    if orc.have_ref():          # the parity target itself, for the record (not the x100 denominator)
-        p = orc.RefV224(64, "port")
-        p.init(0)
-        n = 320
-        t0 = time.perf_counter()
-        for i in range(0, n, 64):
-            p.update(syms[2 * i:2 * (i + 64)], 64)
-        res["port_value"] = round(2 * n / (time.perf_counter() - t0) / 1e6, 6)
-        res["port_sample"] = "%d trellis steps, viterbi224_port.c (oracle/_ref), 1 core" % n
-        p.close()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(nbits_sample):
+    """Reference SSE2 decoder on one host core (falls back to the oracle port restatement).  Two builds of the same
+    reference source are timed where the host can run both -- plain x86-64 (-msse2) and x86-64-v3, the portable
+    stand-in for the reference's -march=native -- and the FASTER one is the baseline."""
+    orc = _orc()
+    rng = np.random.default_rng(1)
+    syms = rng.integers(0, 256, 2 * nbits_sample, dtype=np.uint8)
+    host = host_info()
+    with pinned_to_one_core() as pin:
+        builds = {}
+        if orc.have_ref():
+            variants = ["sse2"]
+            if host["avx2"] and os.path.exists(os.path.join(orc.REF_DIR, "libv224_sse2_v3_ref.so")):
+                variants.append("sse2_v3")
+            for var in variants:
+                d = orc.RefV224(256, var)
+                n = nbits_sample if var == "sse2" else max(512, nbits_sample // 2)
+                dt = _time_ref_update(d, syms, n)
+                d.close()
+                builds[var] = {"Msymbols_per_s": round(2 * n / dt / 1e6, 6), "steps": n, "seconds": round(dt, 2)}
+            best = max(builds, key=lambda v: builds[v]["Msymbols_per_s"])
+            kind, what = "reference", "viterbi224_sse2.c (oracle/_ref, build %s), update_viterbi224_blk" % best
+            value, nb, dt = builds[best]["Msymbols_per_s"], builds[best]["steps"], builds[best]["seconds"]
+        else:
+            os.environ["OMP_NUM_THREADS"] = "1"
+            d = orc.OracleV224(256, orc.FAST)
+            dt = _time_ref_update(d, syms, nbits_sample)
+            d.close()
+            kind, what = "port", "oracle FAST engine (port semantics, SSE2), 1 thread"
+            value, nb = round(2 * nbits_sample / dt / 1e6, 6), nbits_sample
+        res = {"value": value, "unit": "Msymbols/s", "cores": 1, "kind": kind,
+               "sample": "%d trellis steps of uniform-random symbols, %s, %.1f s" % (nb, what, dt),
+               "pinned": {"sched_setaffinity": pin.ok, "core": pin.core}, "host": host}
+        if builds:
+            res["builds"] = builds
+        if orc.have_ref():          # the parity target itself, for the record (not the x100 denominator)
+            p = orc.RefV224(64, "port")
+            p.init(0)
+            n = 320
+            t0 = time.perf_counter()
+            for i in range(0, n, 64):
+                p.update(syms[2 * i:2 * (i + 64)], 64)
+            res["port_value"] = round(2 * n / (time.perf_counter() - t0) / 1e6, 6)
+            res["port_sample"] = "%d trellis steps, viterbi224_port.c (oracle/_ref), 1 core" % n
+            p.close()
     return res
 
 
@@ -106,6 +170,14 @@ def chain_cpu_baseline(iq, fs, binsize, seconds):
     N = 1 << int(np.rint(np.log2(fs / binsize)))
     nsamp = int(seconds * fs) // N * N
     part = np.ascontiguousarray(iq[:2 * nsamp])
+    with pinned_to_one_core() as pin:                 # children (the reference's pipe stages) inherit the one-core mask
+        rec = _chain_cpu_legs(orc, part, nsamp, fs, binsize)
+    rec["pinned"] = {"sched_setaffinity": pin.ok, "core": pin.core}
+    rec["host"] = host_info()
+    return rec
+
+
+def _chain_cpu_legs(orc, part, nsamp, fs, binsize):
     t0 = time.perf_counter()
     bb, _, _, _ = orc.pmdemod(part, samprate=fs, binsize=binsize, want_pre=False)
     t1 = time.perf_counter()
@@ -283,6 +355,59 @@ def chain_workload(a, ctx):
             "roofline": None, "check": {"decoded_run_found_in_sent_stream": ok}}), flush=True)
 
 
+def spawn_ranks(n):
+    """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments>` as a
+    child of this (GPU-free) process; returns its exit code.  Rendezvous on 127.0.0.1 and a free port."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_ranks(a, rank, world):
+    """--dry-ranks: the N-rank path without a device.  Same launcher, same harness calls as the real run (segments dealt
+    to ranks, barrier on both sides of the timed region, MAX over ranks, SUM of 1 = ranks_seen, per-rank times), gloo
+    instead of RCCL, a sleep instead of the decode.  Rank 0 prints the one line."""
+    import torch
+    import torch.distributed as dist
+    load_pkg()
+    from importlib import import_module
+    harness = import_module("isee3_decoder_amd.harness")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    dd = dist if world > 1 else None
+    nseg = world * a.segments_per_gpu
+    mine = harness.shard_segments(nseg, world, rank)
+    units = 1000                                      # stand-in "symbols" per segment and step
+
+    def step():
+        for _ in mine:
+            time.sleep(0.01 * (1 + rank))             # later ranks are slower: the MAX has something to pick
+
+    fence = harness.make_fence(dd, lambda: None)
+    dt_local = harness.timed_steps(step, a.steps, a.warmup, fence)
+    dt = harness.max_over_ranks(dd, torch, dt_local, "cpu")
+    seen = harness.ranks_seen(dd, torch, "cpu")
+    per_rank = harness.gather_per_rank(dd, round(dt_local / a.steps * 1e3, 3))
+    segs = harness.gather_per_rank(dd, mine)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the rank launcher (no device work)", "value": round(units * nseg * a.steps / dt, 1),
+                          "unit": "stand-in units/s", "n_gpus": world, "ranks_seen": seen, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_per_rank": per_rank, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "dry_ranks": True,
+                          "config": {"workload": "sleep stand-in, %d segment(s) per rank" % a.segments_per_gpu,
+                                     "segments_by_rank": segs}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,13 +439,26 @@ def main():
     ap.add_argument("--chain-segments", type=int, default=1,
                     help="> 1: cut ONE capture into this many overlapped segments over all ranks (configs[4])")
     ap.add_argument("--chain-warm-blocks", type=int, default=7)
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="no device work: every rank runs a stand-in step through the same launcher / sharding / fence / MAX "
+                         "code on gloo and rank 0 prints the line (CPU test of the N-rank path)")
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # `python bench.py --gpus N`, N > 1, outside torchrun: start the N ranks ourselves -- as a CHILD process, before this
+    # process has imported torch.cuda or loaded a HIP library (never an exec of a process that touched the GPU)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d -- launch as `python bench.py --gpus N` or as "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (a.gpus, world))
+    if a.dry_ranks:
+        return dry_ranks(a, rank, world)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     # rehearsal mode for a one-GPU box: ISEE3_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
@@ -366,7 +504,7 @@ def main():
             dec.set_option("chunk", chunk)
             decs.append(dec)
         segs.append(dict(dec=decs[0], decs=decs, d_syms=pkg.DeviceBuffer.from_numpy(syms), d_out=pkg.DeviceBuffer(nbits),
-                         bits=bits, noise_mask=noise_mask))
+                         syms=np.ascontiguousarray(syms), bits=bits, noise_mask=noise_mask))
     dec = segs[0]["dec"]
 
     slab = 8 * chunk                                     # bits handed over per call and segment
@@ -421,6 +559,25 @@ def main():
         dec.set_option("profile", 0)
     dt = harness.max_over_ranks(dd, torch, dt_local, redev)
     per_rank = harness.gather_per_rank(dd, round(dt_local / a.steps * 1e3, 3))
+
+    # SURVEY 8(d) config 2's region -- "first kernel enqueue -> last output bit in host memory, H2D of the input
+    # included": ONE more step that starts from host symbols and ends with the bits in a host array.  Reported beside
+    # `value` (which, by the bench contract, is the rate with the inputs resident in HBM).
+    resident_out = segs[0]["d_out"].to_numpy(np.uint8).copy()
+    host_out = [np.empty(nbits, np.uint8) for _ in segs]
+    L = pkg.v224_lib()
+
+    def step_host_buffers():
+        for sg, ho in zip(segs, host_out):
+            if L.v224hip_h2d(sg["d_syms"].ptr, sg["syms"].ctypes.data, sg["syms"].nbytes) != 0:
+                raise RuntimeError("h2d failed")
+        (step_split if a.split > 1 else step_single)()
+        for sg, ho in zip(segs, host_out):
+            if L.v224hip_d2h(ho.ctypes.data, sg["d_out"].ptr, ho.nbytes) != 0:
+                raise RuntimeError("d2h failed")
+
+    dt_host = harness.max_over_ranks(dd, torch, harness.timed_steps(step_host_buffers, 1, 0, fence), redev)
+    host_same = bool(np.array_equal(host_out[0], resident_out))
     d_out, bits, noise_mask = segs[0]["d_out"], segs[0]["bits"], segs[0]["noise_mask"]
 
     # sanity: decoded bits equal sent bits away from the noise blocks (does not replace tests/)
@@ -500,8 +657,13 @@ def main():
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "viterbi224 ACS+chainback streaming, 2^23 states, 8-bit soft syms, "
                                    "decode delay %d, %d symbols per GPU per step" % (a.delay, 2 * nbits),
-                       "residency": "symbols in HBM before the timed region, decoded bits left in HBM (excluded: %.1f MB H2D + "
-                                    "%.1f MB D2H per step, ~1 ms of PCIe)" % (2 * nbits / 1e6, nbits / 1e6),
+                       "residency": "value: symbols resident in HBM when the timed region starts, decoded bits left in HBM "
+                                    "(bench contract); host_buffers: the same step from host symbols to host bits",
+                       "host_buffers": {"value": round(2 * nbits * nseg / dt_host / 1e6, 4), "ms_per_step": round(dt_host * 1e3, 3),
+                                        "steps": 1, "identical_output": host_same,
+                                        "what": "SURVEY 8(d) config 2's region: %.1f MB of symbols H2D (pageable numpy array, "
+                                                "blocking copy), the whole decode, %.1f MB of bits D2H into a host array -- "
+                                                "PCIe inclusive, never the headline" % (2 * nbits / 1e6, nbits / 1e6)},
                        "engine": {0: "simple", 1: "fused", 2: "lds8", 3: "lds15"}[eng],
                        "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8, 3: 15}[eng],
                        "chunk_bits": chunk,

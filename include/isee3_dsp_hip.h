@@ -20,6 +20,7 @@ extern "C" {
 #endif
 
 const char *isee3dsp_last_error(void);
+/* default device of the create / alloc calls of the PROCESS (any thread; atomic), as v224hip_set_device */
 int isee3dsp_set_device(int dev);
 /* Which stream the handles created by the calling thread from now on use: 0 one of their own each (default), 1 ONE
  * stream per device shared by all such handles, 2 the null stream.  The in-process chain uses 1 for pmdemod and 2 for

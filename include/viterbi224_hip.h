@@ -24,8 +24,11 @@ extern "C" {
 #define V224HIP_ENGINE_LDS15  3  /* LDS-staged four-level passes, 15 steps per launch, metrics kept
                                     in a tile-major order between launches                        */
 
-/* Number of HIP devices visible / select the device used by subsequent create calls of this
- * thread (default: device 0, or $V224HIP_DEVICE).  -1 on error. */
+/* Number of HIP devices visible / select the device used by subsequent create calls of the PROCESS, whichever thread
+ * makes them (default: device 0, or $V224HIP_DEVICE).  The setting is one atomic per process -- the design is one process
+ * per GPU, and libisee3chain.so creates its decoders in worker threads that must see the host's choice.  Every other
+ * entry point selects the device its handle was created on, so handles may be used from any thread (one thread at a
+ * time per handle; different handles concurrently).  -1 on error. */
 int v224hip_device_count(void);
 int v224hip_set_device(int dev);
 
@@ -97,7 +100,9 @@ int v224hip_set_option(void *p, const char *key, long value);
 
 /* Counters, read and reset.  "chainback_redone": chainback_viterbi224 / v224hip_decode_frames walk a frame of 512 ..
  * 81 920 bits in 16 pieces at once, each piece checked against the one above it; this counts the pieces that failed the
- * check and were walked again from the true state (the output is the serial walk's either way).  -1 on unknown key. */
+ * check and were walked again from the true state (the output is the serial walk's either way).  Plain reads (inspection):
+ * "dp" = ring index of the next decision row to be written (port.c:24 `dp`), "steps" = trellis steps since init.
+ * -1 on unknown key. */
 long v224hip_get_counter(void *p, const char *key);
 
 /* Block until all enqueued work of this decoder has finished. */

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 
 #pragma GCC visibility push(default)
@@ -24,11 +25,11 @@ extern "C" void pmd_carrier_params(double cstep, uint64_t *u_hi, uint64_t *u_lo,
 #pragma GCC visibility pop
 
 static thread_local char g_err[512] = "";
-static int g_device = -1;
+static std::atomic<int> g_device{-1};    // process-wide default device of create / alloc calls (any thread)
 extern "C" const char *isee3dsp_last_error(void) { return g_err; }
 extern "C" int isee3dsp_set_device(int dev) {
   if (hipSetDevice(dev) != hipSuccess) return -1;
-  g_device = dev;
+  g_device.store(dev, std::memory_order_release);
   return 0;
 }
 #define CHK(expr)                                                                                \
@@ -42,7 +43,7 @@ extern "C" int isee3dsp_set_device(int dev) {
 
 extern "C" void *isee3dsp_dev_alloc(size_t bytes) {
   void *d = nullptr;
-  if (g_device >= 0 && hipSetDevice(g_device) != hipSuccess) return nullptr;
+  { int gd = g_device.load(std::memory_order_acquire); if (gd >= 0 && hipSetDevice(gd) != hipSuccess) return nullptr; }
   if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
   return d;
 }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void k_par_energy(const long long *__restrict_
 extern "C" void *symd_create(int max_samples) {
   Symd *h = (Symd *)calloc(1, sizeof(Symd));
   if (!h) return nullptr;
-  h->dev = g_device >= 0 ? g_device : 0;
+  { int gd = g_device.load(std::memory_order_acquire); h->dev = gd >= 0 ? gd : 0; }
   h->cap = max_samples > 0 ? max_samples : 1;
   CHK(hipSetDevice(h->dev));
   CHK(dsp_stream_create(&h->st, &h->own_st));
@@ -948,10 +949,15 @@ template <int LG, int SRC, bool FIRST, bool PEAK = false>
 static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FT * (R1 > R2 ? R1 : R2);
   const size_t lds = sizeof(double2) * R * FT;
-  static bool attr_set = false;                      // 64 KiB of dynamic LDS at R = 256
-  if (!attr_set) {
+  // 64 KiB of dynamic LDS at R = 256: raised once per device and instantiation (bit d = done on device d; transforms run
+  // from several host threads, a doubled call is harmless, the flag itself is atomic)
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST, PEAK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   if constexpr (PEAK) {
     pk->nparts = c.N / R / FT;
@@ -1006,7 +1012,7 @@ extern "C" void *pmd_create(int fftsize) {
   if (fftsize < 16 || (1 << lg) != fftsize || lg > 24) { snprintf(g_err, sizeof g_err, "pmd_create: fftsize %d not a power of two in [16, 2^24]", fftsize); return nullptr; }
   h = (Pmd *)calloc(1, sizeof(Pmd));
   if (!h) return nullptr;
-  h->dev = g_device >= 0 ? g_device : 0;
+  { int gd = g_device.load(std::memory_order_acquire); h->dev = gd >= 0 ? gd : 0; }
   h->N = fftsize; h->logN = lg;
   CHK(hipSetDevice(h->dev));
   CHK(dsp_stream_create(&h->st, &h->own_st));
@@ -1232,7 +1238,7 @@ extern "C" void *isync_create(int corr_size) {
   if (corr_size < 4096 || (1 << lg) != corr_size || lg > 24) { snprintf(g_err, sizeof g_err, "isync_create: size %d not a power of two in [2^12, 2^24]", corr_size); return nullptr; }
   h = (Isync *)calloc(1, sizeof(Isync));
   if (!h) return nullptr;
-  h->dev = g_device >= 0 ? g_device : 0;
+  { int gd = g_device.load(std::memory_order_acquire); h->dev = gd >= 0 ? gd : 0; }
   h->N = corr_size; h->logN = lg;
   CHK(hipSetDevice(h->dev));
   CHK(dsp_stream_create(&h->st, &h->own_st));

@@ -35,6 +35,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "v224_common.h"
@@ -89,7 +91,9 @@ struct V224 {
   size_t dsyms_off;         // update_viterbi224_blk: next free byte of dsyms (symbols of queued launches stay put)
 };
 
-static int g_device = -1;
+// the PROCESS-WIDE default device of create calls (one process per GPU; the chain library creates its decoders in worker
+// threads, which must see what the host selected): atomic, set by v224hip_set_device from any thread
+static std::atomic<int> g_device{-1};
 
 // Where a decoder's tracebacks run.  MI355X feeds its compute queues through FOUR hardware pipes, and HIP's hardware
 // queues land on them round robin in the order they are created.  Two busy queues on one pipe do not run side by side, and a
@@ -111,7 +115,7 @@ extern "C" int v224hip_device_count(void) {
 }
 extern "C" int v224hip_set_device(int dev) {
   if (hipSetDevice(dev) != hipSuccess) return -1;
-  g_device = dev;
+  g_device.store(dev, std::memory_order_release);
   return 0;
 }
 
@@ -637,18 +641,24 @@ extern "C" void *v224hip_create(int len, int engine, int k) {
   v->K = k > 0 ? k : env_int("V224HIP_K", FUSED_DEFAULT_K);
   if (v->K < 1) v->K = 1;
   if (v->K > FUSED_MAX_K) v->K = FUSED_MAX_K;
-  v->dev = g_device >= 0 ? g_device : env_int("V224HIP_DEVICE", 0);
+  { int gd = g_device.load(std::memory_order_acquire); v->dev = gd >= 0 ? gd : env_int("V224HIP_DEVICE", 0); }
   // whole passes per chunk (1020 = 68 x 15).  With the tracebacks in the pass stream a chunk costs ~35 us of traceback
   // latency whatever its size, and the ring only has to hold delay + ONE chunk: the default doubles at equal memory.
   v->chunk = env_int("V224HIP_CHUNK", v->engine == V224HIP_ENGINE_LDS ? 1024 : (tb_own_stream() ? 1020 : 2040));
   HIPCHK(hipSetDevice(v->dev));
   if (v->engine == V224HIP_ENGINE_LDS15) {       // 133 KiB of dynamic LDS per workgroup: above the default cap
+    // the per-thread parity table of the 15-step kernel, once per device; decoders are created from several threads at
+    // once (chain stages, segment workers): the flag and the upload are under one lock
+    static std::mutex tab_mu;
     static bool tab_done[64] = {false};
-    if (v->dev >= 0 && v->dev < 64 && !tab_done[v->dev]) {     // the per-thread parity table of the 15-step kernel, once per device
-      std::vector<unsigned> tab(4 * 1024);
-      l15_build_rot_tab(tab.data());
-      HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(l15_rot_tab), tab.data(), tab.size() * sizeof(unsigned)));
-      tab_done[v->dev] = true;
+    {
+      std::lock_guard<std::mutex> lk(tab_mu);
+      if (v->dev >= 0 && v->dev < 64 && !tab_done[v->dev]) {
+        std::vector<unsigned> tab(4 * 1024);
+        l15_build_rot_tab(tab.data());
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(l15_rot_tab), tab.data(), tab.size() * sizeof(unsigned)));
+        tab_done[v->dev] = true;
+      }
     }
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_acs_lds15<0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L15_LDS_BYTES));
@@ -1660,7 +1670,10 @@ extern "C" int v224hip_set_option(void *p, const char *key, long value) {
 extern "C" long v224hip_get_counter(void *p, const char *key) {
   V224 *v = (V224 *)p;
   unsigned c = 0;
-  if (!v || !key || strcmp(key, "chainback_redone")) return -1;
+  if (!v || !key) return -1;
+  if (!strcmp(key, "dp")) return (long)v->dp;                           // host-side bookkeeping, nothing to wait for
+  if (!strcmp(key, "steps")) return (long)v->nsteps;
+  if (strcmp(key, "chainback_redone")) return -1;
   HIPCHK(hipSetDevice(v->dev));
   if (v->st2 != v->st) HIPCHK(hipStreamSynchronize(v->st2));
   HIPCHK(hipMemcpyAsync(&c, v->dmisc + 96, sizeof c, hipMemcpyDeviceToHost, v->st));

@@ -52,6 +52,8 @@ int      orc_v224_dp(void *p);                          /* index of next row to 
 uint32_t orc_v224_metric_rel(void *p, uint32_t state);  /* metric[state] - min(metric) */
 uint32_t orc_v224_spread(void *p);                      /* max - min of current metrics */
 uint32_t orc_v224_metric_abs(void *p, int want_max);   /* LITERAL engine only */
+int      orc_v224_set_metrics(void *p, const uint32_t *m_8M);   /* resume from given path metrics (any common offset); dp = 0 */
+int      orc_v224_get_metrics(void *p, uint32_t *out_8M);       /* current metrics minus their minimum */
 uint64_t orc_fnv1a(const void *buf, size_t n);          /* 64-bit FNV-1a, for row hashes */
 
 /* ---- encoder (encode.c:17-35) ---- */

@@ -296,6 +296,30 @@ uint32_t orc_v224_metric_abs(void *p, int want_max) {
   return r;
 }
 
+/* Resume from a given set of path metrics: load 2^23 metrics (state order, any common offset: only their differences
+   enter port.c:171-181) as the current ones and rewind the ring (dp = 0).  The trellis recursion has no other state, so
+   everything decoded from here on is what a decoder that reached these metrics by itself would decode.  Used to pin the
+   product deep inside a 10^7-symbol stream, where running the oracle from the start would take an hour. */
+int orc_v224_set_metrics(void *p, const uint32_t *m) {
+  orc_v224 *v = p;
+  if (!v || !m) return -1;
+  v->dp = 0;
+  if (v->mode == ORC_V224_LITERAL) memcpy(v->m32[v->cur], m, sizeof(uint32_t) * NST);
+  else for (uint32_t i = 0; i < NST; i++) v->m16[v->cur][i] = (uint16_t)m[i];
+  return 0;
+}
+
+/* the current path metrics minus their minimum (same form as the product's v224hip_export_metrics) */
+int orc_v224_get_metrics(void *p, uint32_t *out) {
+  orc_v224 *v = p;
+  if (!v || !out) return -1;
+  uint32_t mn, mx, ref; minmax(v, &mn, &mx, &ref);
+  for (uint32_t i = 0; i < NST; i++)
+    out[i] = v->mode == ORC_V224_LITERAL ? (uint32_t)((int32_t)(v->m32[v->cur][i] - ref) - (int32_t)mn)
+                                         : (uint32_t)((int32_t)(int16_t)(v->m16[v->cur][i] - (uint16_t)ref) - (int32_t)mn);
+  return 0;
+}
+
 uint64_t orc_fnv1a(const void *buf, size_t n) {
   const uint8_t *b = buf;
   uint64_t h = 0xcbf29ce484222325ull;

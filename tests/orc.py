@@ -61,6 +61,8 @@ def lib():
         L.orc_v224_spread.argtypes = [C.c_void_p]
         L.orc_v224_metric_abs.restype = C.c_uint32
         L.orc_v224_metric_abs.argtypes = [C.c_void_p, C.c_int]
+        L.orc_v224_set_metrics.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_v224_get_metrics.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.orc_fnv1a.restype = C.c_uint64
         L.orc_fnv1a.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_encode.restype = C.c_uint64
@@ -180,6 +182,17 @@ class OracleV224(_V224Base):
     def metric_rel(self, state):
         return int(lib().orc_v224_metric_rel(self.h, int(state)))
 
+    def set_metrics(self, m):
+        """resume from the given 2^23 path metrics (uint32, any common offset); rewinds the ring"""
+        m = np.ascontiguousarray(m, dtype=np.uint32)
+        assert m.size == NSTATES
+        assert lib().orc_v224_set_metrics(self.h, m.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+
+    def get_metrics(self):
+        out = np.empty(NSTATES, dtype=np.uint32)
+        assert lib().orc_v224_get_metrics(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+        return out
+
 
 def have_ref():
     return os.path.exists(os.path.join(REF_DIR, "libv224_port_ref.so"))
@@ -207,7 +220,7 @@ class RefV224(_V224Base):
         self.h = L.create_viterbi224(int(length))
         assert self.h
         self.length = length
-        if variant == "sse2":                      # the port implements six of the nine functions
+        if variant.startswith("sse2"):             # the port implements six of the nine functions
             L.decodeword_viterbi224.restype = C.c_uint64
             L.decodeword_viterbi224.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.max_metric_viterbi224.argtypes = [C.c_void_p]

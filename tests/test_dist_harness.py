@@ -90,3 +90,42 @@ def test_two_rank_gloo_segmented_chain_path():
     assert r["segments"] == 15 and r["seams"] == {"matched": 14, "total": 14}
     assert r["equal_to_truth"] and r["nbits"] > 30000
     assert r["mine"] == list(range(0, 15, 2)) and r["calls_rank0"] == 8
+
+
+def _bench_lines(cmd, env=None, timeout=300):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})))
+    return p, [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` (the form the driver types for N = 1) must run TWO ranks: bench.py starts
+    torch.distributed.run as a child before anything touches a device.  --dry-ranks swaps the decode for a sleep and
+    RCCL for gloo; launcher, sharding, fences, MAX and the ranks_seen SUM are the real run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "--steps", "2",
+                        "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line) == 1, "exactly one JSON line, from rank 0"
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and len(r["ms_per_step_per_rank"]) == 2
+    assert r["config"]["segments_by_rank"] == [[0], [1]]
+    # rank 1's stand-in step is twice as long: the reported time is the slowest rank's
+    assert r["ms_per_step"] >= max(r["ms_per_step_per_rank"]) - 1e-3 and r["ms_per_step_per_rank"][1] >= 19.0
+
+
+def test_bench_under_torchrun_is_not_started_twice_and_checks_world_size():
+    """The driver's N > 1 form (torch.distributed.run ... bench.py --gpus N): RANK is set, so bench.py does not spawn
+    again; a --gpus that disagrees with WORLD_SIZE is an error, not a silently smaller run."""
+    p, line = _bench_lines([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
+                            "--gpus", "2", "--dry-ranks", "--steps", "1", "--warmup", "0"])
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    assert len(line) == 1 and json.loads(line[0])["ranks_seen"] == 2
+    p, line = _bench_lines([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-ranks"],
+                           env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and not line and b"WORLD_SIZE is 2" in p.stderr
+    p, line = _bench_lines([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-ranks", "--steps", "1"],
+                           env={})
+    assert p.returncode == 0 and len(line) == 1 and json.loads(line[0])["n_gpus"] == 1

@@ -558,3 +558,46 @@ def test_icesync_correlator_vs_oracle(pkg):
     assert L.isync_search(h, z.ctypes.data, n, 0, 0, n, C.byref(pk), C.byref(mp), None) == 0 and pk.value == pkg.ICESYNC_FAIL
     L.isync_destroy(h)
     co.close()
+
+
+def test_two_host_threads_create_and_run_handles_at_once(pkg):
+    """The bench's and the segment harness's pattern (harness.run_segments(concurrency=2), the chain's stage threads):
+    decoders and pmdemod handles are CREATED and used from two host threads at the same time.  The one-off set-up both
+    create paths share (the 15-step kernel's parity table, the FFT passes' LDS attribute) is under a lock / atomic flag;
+    every thread's results must equal the oracle's / numpy's, round after round."""
+    import threading
+    nbits = 30 * 15 + 7
+    N = 1 << 16
+    work, errors = [], []
+    for t in range(2):
+        syms, _ = orc.gen_coded_frame(7100 + t, nbits, 2.5)
+        o = orc.OracleV224(nbits, orc.FAST)
+        o.init(0); o.update(syms, nbits)
+        iq = np.random.default_rng(40 + t).integers(-30000, 30000, 2 * N).astype(np.int16)
+        work.append((syms, o.chainback(nbits, 0), iq, np.fft.fft(iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64))))
+    gate = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            syms, want, iq, spec = work[t]
+            for rnd in range(4):
+                gate.wait(timeout=120)
+                d = pkg.Viterbi224(nbits)                      # create -> init -> update -> chainback, 15-step engine
+                eng = pkg.PmDemodEngine(N)
+                d.init(0); d.update(syms, nbits)
+                eng.load(iq); eng.fft_peak(0, N)
+                got = d.chainback(nbits, 0)
+                sp = eng.spectrum()
+                d.close(); eng.close()
+                assert np.array_equal(got, want), "thread %d round %d: decoded bytes differ from the oracle" % (t, rnd)
+                assert np.max(np.abs(sp - spec)) <= 1e-12 * np.max(np.abs(spec)), "thread %d round %d: spectrum" % (t, rnd)
+        except Exception as e:                                 # noqa: BLE001
+            errors.append(e)
+            gate.abort()
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors

@@ -715,3 +715,64 @@ def test_progressive_api_refuses_bad_arguments(pkg):
     got, _ = _progressive(pkg, [a, b], syms, 9000, 9000, 200, [4000, 5000])
     assert np.array_equal(got, want)
     a.close(); b.close()
+
+
+@pytest.mark.slow
+def test_deep_stream_pinned_to_the_oracle_at_bench_size(pkg):
+    """BASELINE configs[1] / BASELINE.md B3: the bench's own 10^7-symbol stream, checked against the ORACLE deep inside,
+    not only against itself.  The u16 path metrics are renormalised every second launch and the running offset is
+    carried through 333 k launches; a defect that needs millions of steps to show would pass every shorter test.  At
+    bits ~2.5*10^6 and ~4.9*10^6 the decoder's path metrics are exported (v224hip_export_metrics), the oracle (port
+    semantics, viterbi224_port.c:159-195) is seeded with them (orc_v224_set_metrics: the recursion has no other state)
+    and runs the next 20 000 trellis steps with decodebit(200, 0) per bit: the product's bits over that stretch, the
+    decision rows of its last pass there and all 2^23 relative metrics at its end must equal the oracle's.  The run
+    with the exports must also equal a plain run of the whole stream (exporting switches the metric order and back)."""
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+    nbits, delay, slab, span = 5_000_000, 200, 8160, 20_400       # span = 10 chunks of 2 040 = whole 15-step passes
+    syms, _, _ = synth.coded_stream(1000, nbits, 3.0, 24.0, 1.0)
+    dsy = pkg.DeviceBuffer.from_numpy(syms)
+    d = pkg.Viterbi224(delay + 2040)
+    plain = pkg.DeviceBuffer(nbits)
+    d.init(0)
+    for pos in range(0, nbits, slab):
+        d.stream_decode_dev(dsy, min(slab, nbits - pos), delay, plain, sym_offset=2 * pos, out_offset=pos)
+    d.sync()
+    want_all = plain.to_numpy(np.uint8).copy()
+
+    marks = [2_500_000 // slab * slab, 4_900_000 // slab * slab]
+    stops = sorted(set(marks + [m + span for m in marks]))
+    out = pkg.DeviceBuffer(nbits)
+    snap, last_rows = {}, {}
+    d.init(0)
+    pos = 0
+    while pos < nbits:
+        nxt = min([s for s in stops if s > pos] + [nbits, pos + slab])
+        d.stream_decode_dev(dsy, nxt - pos, delay, out, sym_offset=2 * pos, out_offset=pos)
+        pos = nxt
+        if pos in stops:
+            if pos - span in marks:                    # end of a pinned stretch: rows first (the export below may not move them)
+                dp = d.get_counter("dp")
+                last_rows[pos] = [(j, _fnv(d.export_row((dp - 1 - j) % d.length))) for j in (0, 1, 7, 14, 15, 29)]
+            snap[pos] = d.export_metrics()
+            assert d.get_counter("steps") == pos
+    d.sync()
+    assert np.array_equal(out.to_numpy(np.uint8), want_all), "exporting metrics mid-stream changed the decode"
+
+    for m in marks:
+        o = orc.OracleV224(delay + 1, orc.FAST)
+        o.set_metrics(snap[m])
+        got = want_all[m:m + span]
+        rows_o = {}
+        keep = {span - 1 - j for j, _ in last_rows[m + span]}
+        for u in range(span):
+            o.update(syms[2 * (m + u):2 * (m + u) + 2], 1)
+            if u in keep:
+                rows_o[u] = o.row_hash((o.dp() - 1) % (delay + 1))
+            if u >= delay:                             # the traceback stays inside the rows written since the seed
+                assert o.decodebit(delay, 0) == got[u], "bit %d (%d after the seed at %d) differs from the oracle" % (m + u, u, m)
+        for j, h in last_rows[m + span]:
+            assert rows_o[span - 1 - j] == h, "decision row %d steps before bit %d differs from the oracle" % (j, m + span)
+        assert np.array_equal(o.get_metrics(), snap[m + span]), "path metrics at bit %d differ from the oracle" % (m + span)
+        o.close()
+    d.close()

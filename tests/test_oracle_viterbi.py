@@ -113,3 +113,24 @@ def test_oracle_decodeword_matches_sse2_reference_on_clean_streams():
         got = [o.decodeword(int(d), int(e)) for d, e in z[name + "/queries"]]
         assert got == [int(w) for w in z[name + "/sse2_words"]], name
         o.close()
+
+
+@pytest.mark.parametrize("mode", [orc.FAST, orc.LITERAL], ids=["fast", "literal"])
+def test_oracle_resumes_from_exported_metrics(mode):
+    """orc_v224_set_metrics (the hook the deep-stream GPU test uses): a decoder seeded with another decoder's path
+    metrics -- shifted by a constant, only differences matter (port.c:171-181) -- writes the same decision rows and ends
+    with the same relative metrics as the decoder that ran straight through."""
+    n1, n2 = (120, 90) if mode == orc.FAST else (14, 10)
+    syms, _ = orc.gen_coded_stream(77, n1 + n2, 2.0, 24.0, 0)
+    a = orc.OracleV224(n1 + n2, mode)
+    a.init(0); a.update(syms, n1 + n2)
+    b = orc.OracleV224(n1, mode)
+    b.init(0); b.update(syms[:2 * n1], n1)
+    c = orc.OracleV224(n2, mode)
+    c.set_metrics(b.get_metrics() + np.uint32(777))
+    c.update(syms[2 * n1:], n2)
+    assert c.dp() == 0                                    # ring of n2 rows, written once round
+    for r in range(n2):
+        assert c.row_hash(r) == a.row_hash(n1 + r), "row %d after the resume differs" % r
+    assert np.array_equal(c.get_metrics(), a.get_metrics())
+    assert int(a.get_metrics().min()) == 0 and int(a.get_metrics().max()) == a.spread()
