@@ -70,8 +70,12 @@ int v224hip_stream_decode_shared(void *const *decoders, int ndec, int *holder, c
                                  int delay, uint8_t *out, int warm_bits);
 
 /* The same for a stream that is still ARRIVING (host buffers), with ONE warm-up for the whole stream.  begin() takes the
- * expected length; feed() appends the symbols of the next nbits trellis steps and enqueues whatever can run now (it does
- * not wait for the GPU); decoder 0 decodes from the first symbol on, decoder 1 joins from a fresh init `warm_bits` before
+ * expected length; feed() appends the symbols of the next nbits trellis steps and enqueues whatever can run now.  feed() never
+ * waits for DECODE work; it does wait for its own upload: a blocking hipMemcpy from the caller's (pageable) buffer, which
+ * HIP orders on the legacy null stream -- behind anything the host process has queued there (in libisee3chain.so:
+ * symdemod's short kernels, isee3dsp_share_stream(2)).  That is deliberate: an asynchronous copy would have to ride on the
+ * decoders' own streams (a bubble in a 17 us launch chain per feed, and decoder 1 waiting on an event behind decoder 0's
+ * backlog) or on a fifth busy hardware queue ("One stream per decoder"); decoder 0 decodes from the first symbol on, decoder 1 joins from a fresh init `warm_bits` before
  * the cut and runs to the end.  The cut is placed when decoder 1 can start: x = (expected + warm + what decoder 0 has
  * finished by then) / 2, so that both finish together -- the middle when all symbols are there at once, later when they
  * trickle in, never when one decoder keeps up with them.  end() finishes, verifies the seam as above (decoder 0 decodes

@@ -587,10 +587,11 @@ def chain_lib():
 
 
 def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=200, flip=False,
-              search_freq=0.0, search_width=0.0, stage_ms=None):
+              search_freq=0.0, search_width=0.0, stage_ms=None, out_cap=None):
     """int16 interleaved IQ -> decoded bits as bytes of '0'/'1' (whole chain on the GPU).  `iq` is a numpy array in host
     memory (isee3_chain_run_mem) or a DeviceBuffer holding the capture in HBM (isee3_chain_run_dev).  stage_ms: optional
-    list that receives the ms spent inside the engine calls of [pmdemod, symdemod, vdecode]."""
+    list that receives the ms spent inside the engine calls of [pmdemod, symdemod, vdecode].  out_cap: size of the output
+    buffer handed to the library (default: sized from the capture's duration; tests pass a too small one)."""
     L = chain_lib()
     o = ChainOpts()
     L.isee3_chain_default_opts(C.byref(o))
@@ -610,6 +611,8 @@ def run_chain(iq, samprate=250000.0, binsize=4.0, symrate="1024", decode_delay=2
     else:
         rate = float(symrate) if "." in str(symrate) else float(symrate) * 1024.545058 / 1024.0
     cap = min(nvals // 4 + 4096, int(nvals / 2 / samprate * rate / 2 * 1.1) + 4096)
+    if out_cap is not None:
+        cap = int(out_cap)
     out = C.create_string_buffer(cap)
     n = C.c_size_t(0)
     fn = L.isee3_chain_run_dev if on_dev else L.isee3_chain_run_mem

@@ -14,6 +14,7 @@
 #include <fcntl.h>
 #include <locale.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -414,6 +415,11 @@ static void *pm_thread(void *p) {
 static void *sy_thread(void *p) {
   sy_arg *a = p;
   symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy, sy_slide, sy_put, sy_scan };
+  /* this thread writes into the pipe the Viterbi stage reads: should that stage ever go away first, the write must fail
+   * with EPIPE (a stage error) and not raise SIGPIPE, whose default action would end the HOST program */
+  sigset_t sp;
+  sigemptyset(&sp); sigaddset(&sp, SIGPIPE);
+  pthread_sigmask(SIG_BLOCK, &sp, NULL);
   t_stage_ms = 0;
   a->rc = symdemod_run_blk(&a->o, &e, blk_next, a->in, a->out, stderr);
   a->ms = t_stage_ms;
@@ -433,6 +439,10 @@ static void *vd_thread(void *p) {
   a->rc = vdecode_run(&a->o, &e, a->fd_in, a->out, stderr, &r);
   a->ms = t_stage_ms;
   fflush(a->out);
+  if (a->rc != 0) {                 /* a stage that failed mid-stream: let symdemod finish writing (it stops at its own end of input) */
+    char sink[4096];
+    while (read(a->fd_in, sink, sizeof sink) > 0) {}
+  }
   close(a->fd_in);
   return NULL;
 }
@@ -492,6 +502,10 @@ static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   blk_free(&c1);
   free(pa.src.buf);
   g_stage_ms[0] = pa.ms; g_stage_ms[1] = sa.ms; g_stage_ms[2] = va.ms;
+  if (!pa.rc && !sa.rc && va.rc == -2) {
+    snprintf(g_chain_err, sizeof g_chain_err, "vdecode: the decoded bits could not be written (output buffer too small, or the output was closed)");
+    return 2;
+  }
   if (pa.rc || sa.rc || va.rc) {
     snprintf(g_chain_err, sizeof g_chain_err, "stage failed (pmdemod %d, symdemod %d, vdecode %d): %.80s / %.80s", pa.rc, sa.rc,
              va.rc, isee3dsp_last_error(), v224hip_last_error());

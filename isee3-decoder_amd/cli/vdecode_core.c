@@ -91,7 +91,8 @@ static size_t pass1(const vdecode_opts *o, p1_state *st, const unsigned char *in
 }
 
 /* start-up suppression, output, re-encode statistics, status lines for pairs [j0, j1) (vdecode.c:151-184).
- * -1 when the engine handed back something that is not a bit once start-up is over, or the output cannot be written */
+ * -1 when the engine handed back something that is not a bit once start-up is over, -2 when the output cannot be written
+ * (a closed pipe, a memory stream that is full) */
 static int pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec, const unsigned char *hard,
                   size_t j0, size_t j1, const flip_event *fl, size_t nfl, size_t *f, char *obuf, FILE *out, FILE *err) {
   size_t no = 0;
@@ -120,7 +121,7 @@ static int pass2(const vdecode_opts *o, p2_state *st, const unsigned char *dec, 
   }
   if (no && (fwrite(obuf, 1, no, out) != no || fflush(out) != 0)) {
     fprintf(err, "%s: short write on the output\n", o->argv0);
-    return -1;
+    return -2;
   }
   st->bits_out += no;
   return 0;
@@ -167,7 +168,8 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
       size_t np = pass1(o, &s1, inbuf, (size_t)got, delay, syms, hard, 0, fl, &nfl);
       /* the engine: np trellis steps, one traceback each */
       if (np && e->stream_decode(vd, syms, (int)np, delay, dec) != 0) goto done;
-      if (pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err) != 0) goto done;
+      if ((rc = pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err)) != 0) goto done;
+      rc = -1;
       while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
     }
   } else {
@@ -196,7 +198,8 @@ int vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE 
     free(obuf); obuf = malloc(np + 1);
     if (!dec || !obuf) goto done;
     if (np && (prog ? e->progressive_end(vd, (long long)np, delay, dec) : e->stream_decode_whole(vd, syms, (long long)np, delay, dec)) != 0) goto done;
-    if (pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err) != 0) goto done;
+    if ((rc = pass2(o, &s2, dec, hard, 0, np, fl, nfl, &f, obuf, out, err)) != 0) goto done;
+    rc = -1;
     while (f < nfl) { s2.flips++; f++; if (!o->quiet) fprintf(err, "%s: flipping phase\n", o->argv0); }
   }
   rc = 0;

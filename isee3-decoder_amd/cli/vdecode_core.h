@@ -48,7 +48,8 @@ typedef struct {
 void vdecode_default_opts(vdecode_opts *o);
 /* parse argv like vdecode.c:67-85; returns 0, or -1 on allocation trouble */
 int  vdecode_parse_args(vdecode_opts *o, int argc, char **argv);
-/* run the stage: read symbols from fd_in until EOF, write '0'/'1' to out, status to err */
+/* run the stage: read symbols from fd_in until EOF, write '0'/'1' to out, status to err.  0, -1 (engine / allocation
+ * failure) or -2 (the output could not be written: closed pipe, full memory stream) */
 int  vdecode_run(const vdecode_opts *o, const vdecode_engine *e, int fd_in, FILE *out, FILE *err,
                  vdecode_result *res);
 #endif

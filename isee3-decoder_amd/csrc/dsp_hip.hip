@@ -737,15 +737,17 @@ __device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) 
 }
 // PEAK (the last pass of pmdemod's transform): the |X|^2 arg-max of pmdemod.c:255-279 over bins [pfirst, plast) rides on
 // the pass that produces the bins -- one PeakRec per workgroup -- instead of reading the 16 N bytes of spectrum again
-template <int LG, int SRC, bool FIRST, bool PEAK = false>
-__global__ __launch_bounds__(FT * (PassShape<LG>::R1 > PassShape<LG>::R2 ? PassShape<LG>::R1 : PassShape<LG>::R2))
+// FTC: columns per workgroup (FT = 16 everywhere except where the first pass reads 2- or 4-byte samples: there 32 columns
+// make the read runs 128 bytes -- a whole cache line per row and tile -- instead of 64)
+template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT>
+__global__ __launch_bounds__(FTC * (PassShape<LG>::R1 > PassShape<LG>::R2 ? PassShape<LG>::R1 : PassShape<LG>::R2))
 void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip,
                 double2 *__restrict__ y, const double2 *__restrict__ twA, const double2 *__restrict__ twB,
                 const double2 *__restrict__ twR, int N, int s, int pfirst = 0, int plast = 0, PeakRec *__restrict__ ppart = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2;
-  extern __shared__ double2 Z[];                          // [R2][R1][FT]
-  const int c = threadIdx.x & (FT - 1), r = threadIdx.x >> 4;
-  const int t = blockIdx.x * FT + c, stride = N / R;
+  extern __shared__ double2 Z[];                          // [R2][R1][FTC]
+  const int c = threadIdx.x & (FTC - 1), r = threadIdx.x / FTC;
+  const int t = blockIdx.x * FTC + c, stride = N / R;
   if (r < R2) {                                           // ---- step 1, thread (c, a = r)
     double2 v[R1];
 #pragma unroll
@@ -761,7 +763,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     for (int k1 = 0; k1 < R1; k1++) {
       double2 val = v[brev(k1, lg2c(R1))];
       if (k1 > 0) val = cmul(val, twR[(r * k1) * (256 / R)]);      // W_R^(a k1); a = 0 reads W^0 = 1 exactly
-      Z[(r * R1 + k1) * FT + c] = val;
+      Z[(r * R1 + k1) * FTC + c] = val;
     }
   }
   __syncthreads();
@@ -769,7 +771,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
   if (r < R1) {                                           // ---- step 2, thread (c, k1 = r)
     double2 u[R2];
 #pragma unroll
-    for (int a = 0; a < R2; a++) u[a] = Z[(a * R1 + r) * FT + c];
+    for (int a = 0; a < R2; a++) u[a] = Z[(a * R1 + r) * FTC + c];
     dft_regs<R2>(u);
     const int q = t & (s - 1), ps = t - q;
     double2 *__restrict__ out = y + q + (size_t)R * ps;
@@ -803,7 +805,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     }
   }
   if constexpr (PEAK) {
-    constexpr int TH = FT * (R1 > R2 ? R1 : R2), NW = (TH + 63) / 64;
+    constexpr int TH = FTC * (R1 > R2 ? R1 : R2), NW = (TH + 63) / 64;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const double oe = __shfl_xor(be, o, 64); const int oi = __shfl_xor(bi, o, 64);
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(256) void k_mix(const short2 *__restrict__ iq, cons
   if (threadIdx.x == 0)
     part[blockIdx.x] = make_double2(ws[0].x + ws[1].x + ws[2].x + ws[3].x, ws[0].y + ws[1].y + ws[2].y + ws[3].y);
 }
-__global__ void k_sum2(const double2 *__restrict__ part, int n, double2 *out) {
+__global__ void k_sum2(const double2 *__restrict__ part, int n, double2 *out, double2 *out2 = nullptr) {
   __shared__ double2 ws[256];
   double sr = 0, si = 0;
   for (int i = threadIdx.x; i < n; i += 256) { sr += part[i].x; si += part[i].y; }
@@ -913,7 +915,7 @@ __global__ void k_sum2(const double2 *__restrict__ part, int n, double2 *out) {
     if ((int)threadIdx.x < o) { ws[threadIdx.x].x += ws[threadIdx.x + o].x; ws[threadIdx.x].y += ws[threadIdx.x + o].y; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = ws[0];
+  if (threadIdx.x == 0) { *out = ws[0]; if (out2) *out2 = ws[0]; }
 }
 // pass 2 (pmdemod.c:341-348) + quantise (:360-368)
 __global__ __launch_bounds__(256) void k_rotate(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
@@ -940,15 +942,119 @@ __global__ __launch_bounds__(256) void k_rotate(const short2 *__restrict__ iq, c
   if (threadIdx.x == 0) part[blockIdx.x] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], 0.0);
 }
 
+// ---- the same two passes with the carrier STEPPED instead of evaluated per sample -----------------------------------
+// carrier_at() costs a 128-bit product and a double sincospi per sample, twice per sample and block (both passes form
+// sample * carrier): the two kernels were compute-bound at 0.75 TB/s.  The carrier is a geometric sequence, so a thread
+// seeds ONE closed-form value and multiplies: thread g takes the four consecutive samples 4g .. 4g+3 (one 16-byte load,
+// carriers c, c w1, c w2, c w3 with w_k = carrier_k) and moves on by T = gridDim.x * 256 groups with c *= carrier_{4T}.  Every value
+// is at most CARRIER_RESEED + 1 roundings away from a closed-form one (~2e-16 each; N = 2^23 needs 8 steps per thread),
+// far inside the 1e-9 the spin-down is held to; after CARRIER_RESEED steps the thread seeds again.  Both kernels run the
+// SAME arithmetic on the same grid, so pass 2 re-forms exactly the products pass 1 summed.
+#define CARRIER_RESEED 64
+__global__ void k_carrier_steps(unsigned long long u_hi, unsigned long long u_lo, double logrho, unsigned long long stride,
+                                double2 *__restrict__ cs) {
+  const unsigned t = threadIdx.x;
+  if (t < 4) cs[t] = carrier_at(t < 3 ? (unsigned long long)(t + 1) : stride, u_hi, u_lo, logrho);
+}
+__device__ __forceinline__ void iq_group4(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int g, int flip,
+                                          double2 (&v)[4]) {
+  const uint4 raw = reinterpret_cast<const uint4 *>(iq)[g];
+  const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const short a = (short)(w[k] & 0xffffu), b = (short)(w[k] >> 16);            // short2 {x, y} in memory order
+    double x = flip ? (double)b : (double)a, y = flip ? (double)a : (double)b;
+    if (lo) {                                // buffer[i] *= conj(lophase), as iq_sample
+      const double2 l = lo[4 * g + k];
+      const double pr = l.x, pi = -l.y;
+      const double nx = x * pr - y * pi, ny = x * pi + y * pr;
+      x = nx; y = ny;
+    }
+    v[k] = make_double2(x, y);
+  }
+}
+__global__ __launch_bounds__(256) void k_mix4(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
+                                              unsigned long long u_hi, unsigned long long u_lo, double logrho,
+                                              const double2 *__restrict__ cs, double2 *__restrict__ part) {
+  const double2 w1 = cs[0], w2 = cs[1], w3 = cs[2], wT = cs[3];
+  const int T = gridDim.x * 256, ng = N >> 2;
+  double sr = 0, si = 0;
+  double2 c0 = make_double2(1.0, 0.0);
+  int it = 0;
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += T, it++) {
+    c0 = (it & (CARRIER_RESEED - 1)) == 0 ? carrier_at(4ull * (unsigned long long)g, u_hi, u_lo, logrho) : cmul(c0, wT);
+    double2 v[4];
+    iq_group4(iq, lo, g, flip, v);
+    const double2 c[4] = {c0, cmul(c0, w1), cmul(c0, w2), cmul(c0, w3)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      sr += v[k].x * c[k].x - v[k].y * c[k].y;
+      si += v[k].x * c[k].y + v[k].y * c[k].x;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); si += __shfl_xor(si, o, 64); }
+  __shared__ double2 ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = make_double2(sr, si);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[blockIdx.x] = make_double2(ws[0].x + ws[1].x + ws[2].x + ws[3].x, ws[0].y + ws[1].y + ws[2].y + ws[3].y);
+}
+// pass 2; the block sum of pass 1 is read from device memory (dcsum) and turned into conj(dc) / |dc| here (pmdemod.c:337-338),
+// so that no host round trip separates the two passes
+__global__ __launch_bounds__(256) void k_rotate4(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
+                                                 unsigned long long u_hi, unsigned long long u_lo, double logrho,
+                                                 const double2 *__restrict__ cs, const double2 *__restrict__ dcsum,
+                                                 int16_t *__restrict__ out16, double *__restrict__ pre,
+                                                 double2 *__restrict__ part) {
+  const double2 w1 = cs[0], w2 = cs[1], w3 = cs[2], wT = cs[3];
+  const double2 dcs = *dcsum;
+  const double dcr = dcs.x / N, dci = dcs.y / N;
+  const double amp = hypot(dcr, dci);
+  const double ur = dcr / amp, ui = -dci / amp;
+  const int T = gridDim.x * 256, ng = N >> 2;
+  double acc = 0;
+  double2 c0 = make_double2(1.0, 0.0);
+  int it = 0;
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += T, it++) {
+    c0 = (it & (CARRIER_RESEED - 1)) == 0 ? carrier_at(4ull * (unsigned long long)g, u_hi, u_lo, logrho) : cmul(c0, wT);
+    double2 s0[4];
+    iq_group4(iq, lo, g, flip, s0);
+    const double2 c[4] = {c0, cmul(c0, w1), cmul(c0, w2), cmul(c0, w3)};
+    double q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double2 v = make_double2(s0[k].x * c[k].x - s0[k].y * c[k].y, s0[k].x * c[k].y + s0[k].y * c[k].x);   // what pass 1 summed
+      const double nx = v.x * ur - v.y * ui, ny = v.x * ui + v.y * ur;
+      const double d = nx - amp;
+      acc += d * d;
+      q[k] = ny * 0.70710678118654752440;       // M_SQRT1_2
+    }
+    if (pre) {
+      reinterpret_cast<double2 *>(pre)[2 * g] = make_double2(q[0], q[1]);
+      reinterpret_cast<double2 *>(pre)[2 * g + 1] = make_double2(q[2], q[3]);
+    }
+    const unsigned lo16 = (unsigned)(unsigned short)(short)q[0] | ((unsigned)(unsigned short)(short)q[1] << 16);   // truncation toward zero, as the C cast
+    const unsigned hi16 = (unsigned)(unsigned short)(short)q[2] | ((unsigned)(unsigned short)(short)q[3] << 16);
+    reinterpret_cast<uint2 *>(out16)[g] = make_uint2(lo16, hi16);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ double ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], 0.0);
+}
+
 // what a transform needs besides its data: the twiddle tables of its size and a stream
 struct FftCtx { int N, logN; const double2 *twA, *twB, *twR; hipStream_t st; };
 struct FftSrc { const double2 *x; const void *i16; const double2 *aux; int iparam; };   // see SRC_*: (x) | (iq, lo, flip) | (samples, -, nvalid) | (x, v)
 
 struct PeakAsk { int first, last; PeakRec *part; int nparts; };     // nparts: set by the launch (one per workgroup)
-template <int LG, int SRC, bool FIRST, bool PEAK = false>
+template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT>
 static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
-  constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FT * (R1 > R2 ? R1 : R2);
-  const size_t lds = sizeof(double2) * R * FT;
+  constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FTC * (R1 > R2 ? R1 : R2);
+  const size_t lds = sizeof(double2) * R * FTC;
   // 64 KiB of dynamic LDS at R = 256: raised once per device and instantiation (bit d = done on device d; transforms run
   // from several host threads, a doubled call is harmless, the flag itself is atomic)
   static std::atomic<unsigned long long> attr_set{0};
@@ -956,23 +1062,25 @@ static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, P
   if (hipGetDevice(&dev) != hipSuccess) return -1;
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST, PEAK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST, PEAK, FTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   if constexpr (PEAK) {
-    pk->nparts = c.N / R / FT;
-    k_fft_pass<LG, SRC, FIRST, true><<<c.N / R / FT, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s,
-                                                                      pk->first, pk->last, pk->part);
+    pk->nparts = c.N / R / FTC;
+    k_fft_pass<LG, SRC, FIRST, true, FTC><<<c.N / R / FTC, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s,
+                                                                            pk->first, pk->last, pk->part);
   } else
-    k_fft_pass<LG, SRC, FIRST, false><<<c.N / R / FT, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
+    k_fft_pass<LG, SRC, FIRST, false, FTC><<<c.N / R / FTC, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
   return 0;
 }
 template <int SRC, bool FIRST, bool PEAK = false>
 static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
+  // a first pass over int16 samples (4 or 2 bytes each) takes 32 columns per workgroup where its tile still fits 64 KiB of LDS
+  constexpr bool NARROW = FIRST && (SRC == SRC_IQ || SRC == SRC_REAL16);
   switch (lg) {
-  case 5: return launch_pass<5, SRC, FIRST, PEAK>(c, in, dst, s, pk);
-  case 6: return launch_pass<6, SRC, FIRST, PEAK>(c, in, dst, s, pk);
-  case 7: return launch_pass<7, SRC, FIRST, PEAK>(c, in, dst, s, pk);
+  case 5: return launch_pass<5, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
+  case 6: return launch_pass<6, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
+  case 7: return launch_pass<7, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
   case 8: return launch_pass<8, SRC, FIRST, PEAK>(c, in, dst, s, pk);
   }
   return -1;
@@ -987,7 +1095,7 @@ static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 
   int s = 1;
   if (pk) pk->nparts = 0;
   for (int i = 0; i < npass; i++) {
-    const int lg = base + (i < extra ? 1 : 0);
+    const int lg = base + (i >= npass - extra ? 1 : 0);       // the smaller radices first: 2^23 = 7 + 8 + 8, so that the first pass can take 32 columns
     double2 *dst = ((npass - 1 - i) & 1) == 0 ? out : tmp;
     if (pk && i == npass - 1 && i > 0) { if (launch_pass_lg<SRC_C2, false, true>(c, lg, cur, dst, s, pk) != 0) return -1; }
     else if ((i == 0 ? launch_pass_lg<SRC, true>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false>(c, lg, cur, dst, s)) != 0) return -1;
@@ -1148,7 +1256,28 @@ extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *ou
     const short2 *iq = (const short2 *)h->cur_iq;
     const double2 *lo = h->have_lo ? h->lo : nullptr;
     int nb = (h->N + 255) / 256; if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-    (void)tot;
+    int16_t *o16v = (out16 && out_is_dev) ? out16 : h->d_out16;
+    double *oprev = pre ? (out_is_dev ? pre : h->d_pre) : nullptr;
+    static const bool closed_form = getenv("ISEE3DSP_CARRIER_CLOSED") && atoi(getenv("ISEE3DSP_CARRIER_CLOSED")) != 0;
+    if (!closed_form && h->N >= 1024 && ((uintptr_t)iq & 15u) == 0 && ((uintptr_t)o16v & 7u) == 0 && ((uintptr_t)oprev & 15u) == 0) {
+      // stepped carrier, four samples per thread and step, both passes and their sums without a host round trip in between
+      int nb4 = (h->N / 4 + 255) / 256; if (nb4 > RED_BLOCKS) nb4 = RED_BLOCKS;
+      double2 *cs = tot + 8;
+      k_carrier_steps<<<1, 64, 0, h->st>>>(u_hi, u_lo, logrho, 4ull * (unsigned long long)nb4 * 256ull, cs);
+      k_mix4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, part);
+      k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 128), tot);
+      k_rotate4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, tot, o16v, oprev, part);
+      k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 144));
+      CHK(hipGetLastError());
+      if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
+      if (pre && !out_is_dev) CHK(hipMemcpyAsync(pre, h->d_pre, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
+      CHK(hipStreamSynchronize(h->st));
+      const volatile double *m = (const volatile double *)((char *)h->pin_hdr.h + 128);
+      const double dcr = m[0] / h->N, dci = m[1] / h->N;
+      res->dc_re = dcr; res->dc_im = dci; res->amplitude = hypot(dcr, dci); res->diffsumsq = m[2] / h->N;
+      return 0;
+    }
+    // closed-form carrier per sample (small or unaligned blocks; ISEE3DSP_CARRIER_CLOSED=1)
     k_mix<<<nb, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, part);
     k_sum2<<<1, 256, 0, h->st>>>(part, nb, (double2 *)((char *)h->pin_hdr.d + 128));
     double2 dc;

@@ -27,18 +27,24 @@ def plan_segments(nblocks, nseg, warm_blocks):
     return ([(0, 0, first[-1][2])] if first else []) + rest
 
 
-def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=400, settled=2300, end_guard=64):
+def stitch(parts, overlap_bits, probe_len=160, tail_bits=None, verify_back=400, settled=2300, end_guard=64, delay=200,
+           window_bits=512):
     """parts: decoded bit strings (bytes of '0'/'1') of consecutive overlapping segments;
     overlap_bits[i]: how many decoded bits lie between the start of part i+1 and the cut (its warm-up region).
     A probe is taken from the settled end of that region and located in the previous part -- but only where it
-    can be: part i ends `tail_bits` = (min, max) bits short of the cut (vdecode holds back `delay` bits, symdemod
-    drops the last partial window), so bit w of part i+1 sits at len(part i) + tail - (overlap - w).  The probe must
-    occur exactly ONCE in that range (repetitive telemetry can match one frame off), and with that alignment the two
-    parts must agree on EVERYTHING they share from up to `verify_back` bits before the probe (not before the part's
-    `settled` bit) to the end of part i; otherwise the seam counts as unmatched.
+    can be: part i ends `tail_bits` = (min, max) bits short of the cut, so bit w of part i+1 sits at
+    len(part i) + tail - (overlap - w).  The tail is what the stages hold back at the end of their input: vdecode its
+    `delay` bits (vdecode.c:151-158), symdemod the last partial window (symdemod.c:124-125, up to `window_bits`), so by
+    default tail_bits = (delay - 50, delay + window_bits + 78): the window of possible probe positions is then 768 bits
+    wide, NARROWER than one 1 024-bit minor frame, and exactly repeating frames (idle / fill telemetry) cannot match
+    twice in it.  Every hit inside the window is tried, nearest to the window's middle first, and must hold up over
+    EVERYTHING the two parts share from up to `verify_back` bits before the probe (not before the part's `settled`
+    bit) to the end of part i; a seam where no hit -- or more than one -- verifies counts as unmatched.
     end_guard: the last bits of a part are not compared -- its final symdemod window ran into the end of the input
     (symdemod.c reads whatever its buffer holds there), so they may differ from a decode that had the samples.
     Returns (joined bits, seams matched, seams total)."""
+    if tail_bits is None:
+        tail_bits = (max(0, delay - 50), delay + window_bits + 78)
     out = parts[0]
     ok = 0
     for i, (nxt, ovl) in enumerate(zip(parts[1:], overlap_bits)):
@@ -53,14 +59,20 @@ def stitch(parts, overlap_bits, probe_len=160, tail_bits=(0, 900), verify_back=4
             expect = len(out) - (ovl - w)
             lo = max(0, expect + tail_bits[0] - 64)
             hi = min(len(out), expect + tail_bits[1] + 64 + probe_len)
-            p = out.find(probe, lo, hi)
-            if p < 0 or out.find(probe, p + 1, hi) >= 0:
-                continue                                 # absent, or ambiguous inside the window
-            back = max(0, min(verify_back, w - settled, p))
-            share = max(probe_len + back, len(out) - end_guard - (p - back))
-            if out[p - back:p - back + share] != nxt[w - back:w - back + share]:
-                continue                                 # the alignment does not hold over the rest of the overlap
-            out = out[:p] + nxt[w:]
+            hits, p = [], out.find(probe, lo, hi)
+            while p >= 0:
+                hits.append(p)
+                p = out.find(probe, p + 1, hi)
+            mid = expect + (tail_bits[0] + tail_bits[1]) // 2
+            good = []
+            for p in sorted(hits, key=lambda q: abs(q - mid)):
+                back = max(0, min(verify_back, w - settled, p))
+                share = max(probe_len + back, len(out) - end_guard - (p - back))
+                if out[p - back:p - back + share] == nxt[w - back:w - back + share]:
+                    good.append(p)           # the alignment holds over the rest of the overlap
+            if len(good) != 1:
+                continue                     # absent, or the overlap is periodic inside the window: not decidable here
+            out = out[:good[0]] + nxt[w:]
             placed = True
             break
         if placed:

@@ -16,6 +16,8 @@ static int eng_stream(void *h, const unsigned char *syms, int nbits, int delay, 
     orc_v224_update(h, syms + 2 * i, 1);
     steps++;
     out[i] = steps >= (unsigned long long)delay ? (unsigned char)orc_v224_decodebit(h, delay, 0) : 0xff;
+    /* fault injection: an engine that hands back "no bit" for one trellis step after start-up */
+    if (getenv("VDECODE_TEST_BADBIT") && steps == strtoull(getenv("VDECODE_TEST_BADBIT"), NULL, 10)) out[i] = 0xff;
   }
   return 0;
 }
@@ -49,7 +51,13 @@ int main(int argc, char **argv) {
   vdecode_engine e = { eng_create, eng_init, eng_stream, eng_destroy, 0, eng_whole, eng_limit, NULL, NULL };
   o.whole_input = getenv("VDECODE_WHOLE") && atoi(getenv("VDECODE_WHOLE"));
   if (o.whole_input && atoi(getenv("VDECODE_WHOLE")) == 2) { e.progressive_feed = eng_feed; e.progressive_end = eng_end; }
-  int rc = vdecode_run(&o, &e, 0, stdout, stderr, &r);
-  fprintf(stderr, "RESULT bits=%llu symerrs=%llu flips=%d\n", r.bits_out, r.symerrs_total, r.flips);
-  return rc ? 2 : 0;
+  /* VDECODE_TEST_OUTCAP=n: the output is a memory stream of n bytes, as in isee3_chain_run_mem with a short buffer */
+  FILE *out = stdout;
+  char *mem = NULL;
+  size_t cap = getenv("VDECODE_TEST_OUTCAP") ? strtoul(getenv("VDECODE_TEST_OUTCAP"), NULL, 10) : 0;
+  if (cap) { mem = malloc(cap); out = fmemopen(mem, cap, "w"); setvbuf(out, NULL, _IONBF, 0); }
+  int rc = vdecode_run(&o, &e, 0, out, stderr, &r);
+  if (cap) { long n = ftell(out); fclose(out); fwrite(mem, 1, n > 0 ? (size_t)n : 0, stdout); free(mem); }
+  fprintf(stderr, "RESULT rc=%d bits=%llu symerrs=%llu flips=%d\n", rc, r.bits_out, r.symerrs_total, r.flips);
+  return rc == -2 ? 3 : rc ? 2 : 0;
 }

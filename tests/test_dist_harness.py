@@ -70,6 +70,17 @@ def test_stitch_locates_the_seam_by_position_and_verifies_it():
     per = frame * 24
     out, ok, tot = segment.stitch([per[:9000 - 300], per[9000 - ovl:20000]], [ovl])
     assert ok == 1 and out == per[:20000]
+    # ... at EVERY tail the stages can leave (vdecode's delay .. delay + one symdemod window): the window of possible
+    # positions is narrower than a frame, so a frame-periodic stream never matches twice
+    for tail in range(200, 713, 32):
+        out, ok, tot = segment.stitch([per[:9000 - tail], per[9000 - ovl:20000]], [ovl])
+        assert ok == 1 and out == per[:20000], tail
+    # a probe that occurs twice inside the window but whose overlap verifies only once: placed, not rejected as ambiguous
+    twice = bytearray(full)
+    twice[9000 - ovl + 3200 + 300:9000 - ovl + 3200 + 300 + 160] = full[9000 - ovl + 3200:9000 - ovl + 3360]
+    twice = bytes(twice)
+    out, ok, tot = segment.stitch([twice[:9000 - 400], junk + twice[9000 - ovl + 2100:18000]], [ovl])
+    assert ok == 1 and out == twice[:18000]
 
 
 def test_two_rank_gloo_segmented_chain_path():

@@ -601,3 +601,80 @@ def test_two_host_threads_create_and_run_handles_at_once(pkg):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_chain_output_buffer_too_small_is_an_error_in_every_mode(pkg, monkeypatch):
+    """isee3_chain_run_mem / _dev with an output buffer that cannot take the decoded bits: rc 2 and a message that says
+    so -- never a truncated result -- in block mode (the Viterbi stage stops at its first short write while symdemod is
+    still producing symbols) and in progressive / whole mode (noticed when pass 2 writes at the end).  A good call
+    afterwards on the same kept objects gives the full result."""
+    fs = 32768.0
+    iq, _ = orc.gen_iq(95, fs, 30.0, fc_hz=2345.6, amp=3000.0, cn0_dbhz=48.0)
+    monkeypatch.setenv("ISEE3_CHAIN_MODE", "block")
+    want = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
+    assert len(want) > 14000
+    for mode in ("block", "progressive", "whole"):
+        monkeypatch.setenv("ISEE3_CHAIN_MODE", mode)
+        for cap in (1000, len(want) - 1):
+            with pytest.raises(RuntimeError, match="could not be written"):
+                pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024", out_cap=cap)
+        assert pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024", out_cap=len(want) + 1) == want, mode
+
+
+def test_c_host_survives_a_stage_that_fails_mid_stream(pkg, tmp_path):
+    """The same failure seen from a C program, where SIGPIPE still has its default action (Python ignores it): the
+    Viterbi stage gives up while symdemod is writing into the pipe between them.  The host must get rc 2 back and go
+    on living (the stage drains the pipe before closing it; symdemod's thread blocks SIGPIPE)."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "chain_smallcap_host")
+    lib = os.path.join(ROOT, "isee3-decoder_amd", "lib")
+    subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tests", "csrc", "chain_smallcap_host.c"), "-L" + lib,
+                    "-lisee3chain", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    fs = 32768.0
+    iq, _ = orc.gen_iq(96, fs, 60.0, fc_hz=-3456.7, amp=3000.0, cn0_dbhz=48.0)
+    for mode in ("block", "progressive"):
+        p = subprocess.run([exe, str(fs), "1", "700"], input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=300, env=dict(os.environ, ISEE3_CHAIN_MODE=mode))
+        assert p.returncode == 0, (mode, p.returncode, p.stderr[-500:])
+        assert p.stdout.startswith(b"rc=2 ") and b"could not be written" in p.stdout, p.stdout
+    p = subprocess.run([exe, str(fs), "1", "40000"], input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith(b"rc=0 n=") and int(p.stdout.split()[1][2:]) > 29000, p.stdout
+
+
+@pytest.mark.slow
+def test_config4_chain_at_10_msps_end_to_end(pkg):
+    """BASELINE configs[4] at its real shape: 10 MS/s int16 IQ, `-b 1` => N = 2^23 (pmdemod.c:129-131), `-W 0` full-band
+    search (:273-276), 9 760 samples per symbol and 10 M-sample symdemod windows (symdemod.c:89-125).  24 blocks (20.1 s,
+    805 MB of IQ) through the in-process chain -- block ring in HBM, device window store, progressive Viterbi stage --
+    (a) from host memory and resident in HBM: identical; (b) == the ORACLE chain (pmdemod restatement | symdemod | vdecode,
+    port semantics) bit for bit; (c) cut into 6 block-aligned segments with a 7-block warm-up (the first two start at
+    block 0 and are one segment: 5 segments, 4 seams), decoded independently two at a time and stitched: every seam
+    verified, result == the single pass."""
+    from importlib import import_module
+    seg = import_module("isee3_decoder_amd.segment")
+    fs, N, nblk = 10_000_000.0, 1 << 23, 24
+    iq, sent = orc.gen_iq(98, fs, nblk * N / fs + 1e-3, fc_hz=2_345_678.9, amp=3000.0,
+                          cn0_dbhz=45.0 + 10 * math.log10(fs / 250000.0))
+    iq = np.ascontiguousarray(iq[:2 * nblk * N])
+    single = pkg.run_chain(iq, samprate=fs, binsize=1.0, symrate="1024")
+    d_iq = pkg.DeviceBuffer.from_numpy(iq)
+    assert pkg.run_chain(d_iq, samprate=fs, binsize=1.0, symrate="1024") == single
+    d_iq.free()
+    assert len(single) > 9000
+    got = "".join(map(str, np.frombuffer(single, np.uint8)[3000:4000] - ord("0")))
+    assert got in "".join(map(str, sent)), "decoded run not found in the sent telemetry"
+    # (b) the oracle chain on the same capture
+    bb, _, rep, n2 = orc.pmdemod(iq, samprate=fs, binsize=1.0, want_pre=False)
+    assert n2 == N and len(rep) == nblk
+    sy, _, _ = orc.symdemod(bb, samprate=int(fs), c_opt="1024")
+    del bb
+    ref, _ = orc.vdecode(sy)
+    assert single == ref, "GPU chain differs from the oracle chain at 10 MS/s"
+    # (c) overlapped segments
+    bits, ok, seams, processed = seg.decode_segmented(iq, fs, 1.0, 6, pkg.run_chain, warm_blocks=7, concurrency=2)
+    assert (seams, ok) == (4, 4)
+    assert processed == (8 + 4 * 11) * N
+    n = min(len(bits), len(single))
+    assert n > 9000 and bits[:n - 64] == single[:n - 64]
+    pkg.release_chain_objects()

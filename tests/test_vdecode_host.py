@@ -87,3 +87,27 @@ def test_reencode_symbol_error_statistic_matches_reference_stderr(harness, name,
     want = status_lines(z[name + "/stderr"].tobytes())
     assert any("symerrs" in ln for ln in want)
     assert status_lines(p.stderr) == want
+
+
+@pytest.mark.parametrize("whole", ["0", "1", "2"], ids=["blockwise", "whole_input", "progressive"])
+def test_engine_fault_and_short_output_are_errors_not_truncation(harness, whole):
+    """pass 2's guards (vdecode_core.c): an engine that hands back something that is not a bit after start-up is an
+    engine error (-1); an output that cannot take the bits -- the chain's memory stream with too small a buffer -- is
+    reported as -2, distinct from it, and nothing is silently dropped.  In all three ways the stage takes its input."""
+    z = np.load(G)
+    name = "F_noflip" if "F_noflip" in _names() else _names()[0]
+    syms, want = z[name + "/syms"].tobytes(), z[name + "/stdout"].tobytes()
+    env = dict(os.environ, VDECODE_WHOLE=whole)
+    p = subprocess.run([harness, "-q"] + _args(z, name), input=syms, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=dict(env, VDECODE_TEST_BADBIT="700"))
+    assert p.returncode == 2 and b"returned no bit for trellis step 699" in p.stderr and b"RESULT rc=-1" in p.stderr
+    assert want.startswith(p.stdout) and len(p.stdout) < len(want)
+    cap = len(want) - 100
+    p = subprocess.run([harness, "-q"] + _args(z, name), input=syms, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=dict(env, VDECODE_TEST_OUTCAP=str(cap)))
+    assert p.returncode == 3 and b"short write on the output" in p.stderr and b"RESULT rc=-2" in p.stderr
+    # (what did fit is a prefix of the true output; glibc's memory stream ends a full buffer with a NUL byte)
+    assert len(p.stdout) <= cap and want.startswith(p.stdout.rstrip(b"\0"))
+    p = subprocess.run([harness, "-q"] + _args(z, name), input=syms, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=dict(env, VDECODE_TEST_OUTCAP=str(len(want) + 1)))
+    assert p.returncode == 0 and p.stdout == want
