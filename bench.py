@@ -218,6 +218,41 @@ def chain_check(bits, sent):
     return len(got), bool(len(got) > 2500 and "".join(map(str, got[-1100:-100])) in s)
 
 
+def chain_roofline(fs, binsize, nsamp_step, dt_step, stage_ms=None):
+    """HBM roofline of the whole chain: physical bytes per IQ sample and stage from the committed PMC passes
+    (profiles/r03_pmc_chain.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH x 2 on gfx950 as the
+    guide prescribes, summed by kernel and divided by the samples those runs processed) x the samples of this step /
+    this step's wall time, against the 8 TB/s peak; SURVEY 8(d)'s algorithmic 8 + (symrate / fs) x 17 301 504 B per sample
+    beside it.  None when no PMC record matches this sample rate / bin size."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_chain.json")
+    if not os.path.exists(path):
+        return None
+    for e in json.load(open(path)).get("configs", []):
+        if abs(e["samprate"] - fs) < 0.5 and abs(e["binsize"] - binsize) < 1e-9:
+            break
+    else:
+        return None
+    bps = e["hbm_bytes_per_sample"]
+    total = float(sum(bps.values()))
+    traffic = total * nsamp_step
+    alg = 8.0 + 1024.545058 / fs * 17301504.0
+    r = {"bound": "hbm", "achieved": round(traffic / dt_step / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(traffic / dt_step / 1e9 / HBM_PEAK_GBS, 4), "traffic": int(traffic),
+         "traffic_unit": "HBM bytes per step, all kernels of the chain: PMC bytes per sample (%s) x %d samples" % (e["source"], nsamp_step),
+         "hbm_bytes_per_sample": {k: round(v, 1) for k, v in bps.items()},
+         "algorithmic_bytes_per_sample": round(alg, 1),
+         "algorithmic_GBps": round(alg * nsamp_step / dt_step / 1e9, 1),
+         "physical_over_algorithmic": round(total / alg, 3)}
+    if stage_ms:
+        r["stages"] = {st: {"hbm_bytes": int(bps.get(st, 0.0) * nsamp_step), "engine_ms": round(ms, 3),
+                            "GBps_over_engine_time": round(bps.get(st, 0.0) * nsamp_step / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+                       for st, ms in zip(("pmdemod", "symdemod", "viterbi"), stage_ms)}
+        r["stages"]["what"] = ("engine_ms = time the stage's host thread spent inside engine calls in the last timed step (waits "
+                               "included; the three stages run at the same time on the one GPU, so their rates do not add up to "
+                               "`achieved`)")
+    return r
+
+
 def chain_record(a, ctx, seconds, rate, binsize, steps, warmup, with_cpu):
     """BASELINE configs[2] / [3]: the whole chain on one independent capture per rank.  Timed with the capture resident
     in HBM (the contract's `value`) and again with the capture in host memory (PCIe inclusive)."""
@@ -260,6 +295,7 @@ def chain_record(a, ctx, seconds, rate, binsize, steps, warmup, with_cpu):
            "algorithmic_bytes_per_sample": {"pmdemod": 6, "symdemod": 2,
                                             "viterbi": round(1024.545058 / fs * 17301504, 1)},
            "check": {"decoded_run_found_in_sent_stream": ok}}
+    rec["roofline"] = chain_roofline(fs, binsize, nsamp * world, dt / steps, ms)
     if with_cpu:
         rec["cpu_baseline"] = chain_cpu_baseline(iq, fs, binsize, a.chain_cpu_seconds)
         rec["speedup_vs_cpu_1core"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
@@ -306,17 +342,29 @@ def chain_workload(a, ctx):
         rec = chain_record(a, ctx, a.chain_seconds, a.chain_rate, a.chain_bin, a.steps, a.warmup, not a.no_cpu and world == 1)
         if rank == 0:
             rec.update({"n_gpus": world, "ranks_seen": ctx["ranks_seen"], "higher_is_better": True, "scaling": "weak",
-                        "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic", "config": {"workload": rec.pop("workload")},
-                        "roofline": None})
+                        "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic", "config": {"workload": rec.pop("workload")}})
             print(json.dumps(rec), flush=True)
         return
-    from importlib import import_module
-    segmod = import_module("isee3_decoder_amd.segment")
     fs = float(a.chain_rate)
     iq, sent = synth.iq_capture(3, fs, a.chain_seconds, amp=None)        # the same capture on every rank
-    N = 1 << int(np.rint(np.log2(fs / a.chain_bin)))
+    rec = segmented_record(a, ctx, iq, sent, fs, a.chain_bin, a.chain_segments, a.chain_warm_blocks, a.steps, a.warmup)
+    if rank == 0:
+        rec.update({"n_gpus": world, "ranks_seen": ctx["ranks_seen"], "higher_is_better": True, "vs_baseline": None,
+                    "dtype": "f64+u16", "data": "synthetic"})
+        print(json.dumps(rec), flush=True)
+
+
+def segmented_record(a, ctx, iq, sent, fs, binsize, nseg, warm_blocks, steps, warmup):
+    """BASELINE configs[4]: ONE capture (the same array on every rank, resident in HBM) cut into nseg overlapped
+    block-aligned segments, segment g -> rank g mod world, two chains at a time per GPU, the decoded parts all-gathered
+    (a few kB: the only exchange) and stitched on rank 0 with every seam verified.  Strong scaling: the capture is fixed."""
+    pkg, harness, dist, torch = ctx["pkg"], ctx["harness"], ctx["dist"], ctx["torch"]
+    rank, world, redev = ctx["rank"], ctx["world"], ctx["redev"]
+    from importlib import import_module
+    segmod = import_module("isee3_decoder_amd.segment")
+    N = 1 << int(np.rint(np.log2(fs / binsize)))
     nblocks = (len(iq) // 2) // N
-    plan = segmod.plan_segments(nblocks, a.chain_segments, a.chain_warm_blocks)
+    plan = segmod.plan_segments(nblocks, nseg, warm_blocks)
     mine = harness.shard_segments(len(plan), world, rank)
     d_iq = pkg.DeviceBuffer.from_numpy(iq)
     out = {}
@@ -325,34 +373,53 @@ def chain_workload(a, ctx):
         view = pkg.DeviceBuffer.__new__(pkg.DeviceBuffer)            # a window into the resident capture
         view.ptr, view.nbytes = d_iq.ptr + 4 * b0 * N, 4 * (b1 - b0) * N
         try:
-            return pkg.run_chain(view, samprate=fs, binsize=a.chain_bin, symrate="1024", decode_delay=a.delay)
+            return pkg.run_chain(view, samprate=fs, binsize=binsize, symrate="1024", decode_delay=a.delay)
         finally:
             view.ptr = None
 
     def step():
         out["parts"] = harness.run_segments(plan, mine, run_one, concurrency=2)
 
-    fence = harness.make_fence(dist if world > 1 else None, torch.cuda.synchronize)
-    dt_local = harness.timed_steps(step, a.steps, a.warmup, fence)
-    dt = harness.max_over_ranks(dist if world > 1 else None, torch, dt_local, redev)
-    per_rank = harness.gather_per_rank(dist if world > 1 else None, round(dt_local / a.steps * 1e3, 3))
-    bits, seams = harness.gather_and_stitch(dist if world > 1 else None, plan, out["parts"], N / fs * 1024.545058 / 2,
-                                            segmod.stitch)
-    if rank == 0:
-        nbits, ok = chain_check(bits, sent)
-        nsamp = len(iq) // 2
-        print(json.dumps({
-            "metric": "end-to-end IQ Msamples/s", "value": round(nsamp * a.steps / dt / 1e6, 3), "unit": "Msamples/s",
-            "n_gpus": world, "ranks_seen": ctx["ranks_seen"], "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_per_rank": per_rank, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64+u16", "data": "synthetic",
-            "config": {"workload": "ONE capture of %g s of %g kS/s int16 IQ (%g Hz bins) cut into %d overlapped block-aligned "
-                                   "segments (%d after merging those that start at block 0), warm-up %d blocks, segment g -> "
-                                   "rank g mod %d, two chains at a time per GPU, capture resident in HBM, stitched on rank 0"
-                                   % (a.chain_seconds, fs / 1e3, a.chain_bin, a.chain_segments, len(plan), a.chain_warm_blocks, world),
+    dd = dist if world > 1 else None
+    fence = harness.make_fence(dd, torch.cuda.synchronize)
+    dt_local = harness.timed_steps(step, steps, warmup, fence)
+    dt = harness.max_over_ranks(dd, torch, dt_local, redev)
+    per_rank = harness.gather_per_rank(dd, round(dt_local / steps * 1e3, 3))
+    bits, seams = harness.gather_and_stitch(dd, plan, out["parts"], N / fs * 1024.545058 / 2, segmod.stitch)
+    d_iq.free()
+    if rank != 0:
+        return None
+    nbits, ok = chain_check(bits, sent)
+    nsamp = nblocks * N
+    processed = int(sum((b1 - b0) * N for b0, _, b1 in plan))
+    return {"metric": "end-to-end IQ Msamples/s", "value": round(nsamp * steps / dt / 1e6, 3), "unit": "Msamples/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_per_rank": per_rank,
+            "scaling": "strong",
+            "config": {"workload": "ONE capture of %d blocks of 2^%d samples (%.1f s of %g kS/s int16 IQ, %g Hz bins, full-band "
+                                   "carrier search) cut into %d overlapped block-aligned segments (%d after merging those that "
+                                   "start at block 0), warm-up %d blocks, segment g -> rank g mod %d, two chains at a time per "
+                                   "GPU, capture resident in HBM, stitched on rank 0"
+                                   % (nblocks, int(np.log2(N)), nsamp / fs, fs / 1e3, binsize, nseg, len(plan), warm_blocks, world),
                        "decoded_bits": nbits, "segments": len(plan), "seams": seams,
-                       "samples_processed_incl_overlap": int(sum((b1 - b0) * N for b0, _, b1 in plan))},
-            "roofline": None, "check": {"decoded_run_found_in_sent_stream": ok}}), flush=True)
+                       "samples_processed_incl_overlap": processed,
+                       "processed_rate_Msamples_per_s": round(processed * steps / dt / 1e6, 3)},
+            "roofline": chain_roofline(fs, binsize, processed, dt / steps),
+            "check": {"decoded_run_found_in_sent_stream": ok, "all_seams_verified": bool(seams and seams["matched"] == seams["total"])}}
+
+
+def stress_record(a, ctx):
+    """BASELINE configs[4] in the default line: 10 MS/s, 1 Hz bins (N = 2^23), 64 overlapped segments of one block each
+    (+ 7 warm-up blocks), full-band search.  The 64-block capture (2.1 GB) is generated once, in parallel."""
+    synth = ctx["synth"]
+    fs, N = 1.0e7, 1 << 23
+    workers = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, ctx["world"])))
+    t0 = time.perf_counter()
+    iq, sent = synth.iq_capture_parallel(3, fs, a.stress_blocks * N, workers=workers)
+    gen_s = time.perf_counter() - t0
+    rec = segmented_record(a, ctx, iq, sent, fs, 1.0, a.stress_segments, 7, max(1, min(a.steps, 2)), 1)
+    if rec is not None:
+        rec["capture_generated_in_s"] = round(gen_s, 1)
+    return rec
 
 
 def spawn_ranks(n):
@@ -439,6 +506,9 @@ def main():
     ap.add_argument("--chain-segments", type=int, default=1,
                     help="> 1: cut ONE capture into this many overlapped segments over all ranks (configs[4])")
     ap.add_argument("--chain-warm-blocks", type=int, default=7)
+    ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] record (10 MS/s, 64 overlapped segments)")
+    ap.add_argument("--stress-blocks", type=int, default=64)
+    ap.add_argument("--stress-segments", type=int, default=64)
     ap.add_argument("--dry-ranks", action="store_true",
                     help="no device work: every rank runs a stand-in step through the same launcher / sharding / fence / MAX "
                          "code on gloo and rank 0 prints the line (CPU test of the N-rank path)")
@@ -600,6 +670,10 @@ def main():
         chain = chain_record(a, ctx, a.chain_seconds, a.chain_rate, a.chain_bin, a.chain_steps or a.steps, max(1, a.warmup),
                              world == 1 and not a.no_cpu)
         pkg.release_chain_objects()
+    stress = None
+    if not a.no_chain and not a.no_stress:
+        stress = stress_record(a, ctx)
+        pkg.release_chain_objects()
 
     if rank == 0:
         total_syms = 2 * nbits * nseg * a.steps
@@ -685,6 +759,8 @@ def main():
             res["frames"] = frames
         if chain is not None:
             res["chain"] = chain
+        if stress is not None:
+            res["stress"] = stress
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

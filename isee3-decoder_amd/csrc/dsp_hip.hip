@@ -768,6 +768,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
   }
   __syncthreads();
   double be = -1.0; int bi = -1;
+  double2 u_first[FIRST ? R2 : 1];                        // a first stage's results (see the transposed store below)
   if (r < R1) {                                           // ---- step 2, thread (c, k1 = r)
     double2 u[R2];
 #pragma unroll
@@ -796,13 +797,31 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
         else val = cmul(val, tw2((unsigned)ps * (unsigned)k));
       }
       if (walk) wk = cmul(wk, wstep);
-      out[(size_t)k * s] = val;
+      if constexpr (FIRST) u_first[k2] = val;               // parked: leaves through the LDS transpose below
+      else out[(size_t)k * s] = val;
       if constexpr (PEAK) {
         const int i = q + R * ps + k * s;                   // the bin this value is (the last pass: N fits an int)
         const double e = val.x * val.x + val.y * val.y;
         if (i >= pfirst && i < plast && peak_better(e, i, be, bi)) { be = e; bi = i; }
       }
     }
+  }
+  if constexpr (FIRST) {
+    // First stage (s = 1): the tile's output is ONE contiguous block of FTC * R elements, y[R t + k] -- but thread (c, k1)
+    // holds k = k1 + R1 k2 of column c, so a store instruction straight from registers would scatter 32- or 64-byte pieces
+    // over FTC columns R * 16 bytes apart (measured: the pass ran at 1.5 TB/s, bound by exactly that).  The values go
+    // through LDS once more (column-major rows of R + 1 elements: no bank conflict either way) and leave as 1 KiB per wave
+    // instruction.  (PEAK never rides on a first pass: fft_forward.)
+    constexpr int TH = FTC * (R1 > R2 ? R1 : R2);
+    __syncthreads();                                        // every thread has pulled its part of Z
+    if (r < R1) {
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) Z[c * (R + 1) + r + R1 * k2] = u_first[k2];
+    }
+    __syncthreads();
+    double2 *__restrict__ blk = y + (size_t)R * ((size_t)blockIdx.x * FTC);
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < FTC * R; idx += TH) blk[idx] = Z[(idx / R) * (R + 1) + (idx % R)];
   }
   if constexpr (PEAK) {
     constexpr int TH = FTC * (R1 > R2 ? R1 : R2), NW = (TH + 63) / 64;
@@ -1054,7 +1073,7 @@ struct PeakAsk { int first, last; PeakRec *part; int nparts; };     // nparts: s
 template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT>
 static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FTC * (R1 > R2 ? R1 : R2);
-  const size_t lds = sizeof(double2) * R * FTC;
+  const size_t lds = sizeof(double2) * (FIRST ? R + 1 : R) * FTC;      // a first stage re-uses the tile as its padded output image
   // 64 KiB of dynamic LDS at R = 256: raised once per device and instantiation (bit d = done on device d; transforms run
   // from several host threads, a doubled call is harmless, the flag itself is atomic)
   static std::atomic<unsigned long long> attr_set{0};
@@ -1095,7 +1114,10 @@ static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 
   int s = 1;
   if (pk) pk->nparts = 0;
   for (int i = 0; i < npass; i++) {
-    const int lg = base + (i >= npass - extra ? 1 : 0);       // the smaller radices first: 2^23 = 7 + 8 + 8, so that the first pass can take 32 columns
+    // the larger radices first (2^23 = 8 + 8 + 7).  ISEE3DSP_FFT_ORDER=asc puts the smaller ones first (7 + 8 + 8: the first
+    // pass then takes 32 columns = 128-byte read runs): measured at 2^23, 102 + 72 + 67 us against 98 + 73 + 60
+    static const bool asc = getenv("ISEE3DSP_FFT_ORDER") && getenv("ISEE3DSP_FFT_ORDER")[0] == 'a';
+    const int lg = base + ((asc ? i >= npass - extra : i < extra) ? 1 : 0);
     double2 *dst = ((npass - 1 - i) & 1) == 0 ? out : tmp;
     if (pk && i == npass - 1 && i > 0) { if (launch_pass_lg<SRC_C2, false, true>(c, lg, cur, dst, s, pk) != 0) return -1; }
     else if ((i == 0 ? launch_pass_lg<SRC, true>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false>(c, lg, cur, dst, s)) != 0) return -1;

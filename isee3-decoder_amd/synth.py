@@ -59,6 +59,19 @@ def telemetry_bits(seed, nbits):
     return bits
 
 
+def _iq_range(sy, s, e, samprate, fc_hz, beta, symrate, amp, sigma, phi0, rng, out):
+    """samples [s, e) of the capture into out[0 : 2 (e - s)] (signal = a function of the absolute sample index)"""
+    i = np.arange(s, e, dtype=np.float64)
+    ph = i * (symrate / samprate)
+    k = ph.astype(np.int64)
+    m = np.where(ph - k < 0.5, -1.0, 1.0) * sy[k]
+    th = np.mod(i * (2 * np.pi * fc_hz / samprate), 2 * np.pi) + phi0 + beta * m
+    x = amp * np.cos(th) + rng.normal(0, sigma, e - s)
+    y = amp * np.sin(th) + rng.normal(0, sigma, e - s)
+    out[0:2 * (e - s):2] = np.clip(np.rint(x), -32767, 32767).astype(np.int16)
+    out[1:2 * (e - s):2] = np.clip(np.rint(y), -32767, 32767).astype(np.int16)
+
+
 def iq_capture(seed, samprate, seconds, fc_hz=12345.678, beta=1.1, symrate=ACTUALCLOCK, amp=3000.0,
                cn0_dbhz=45.0, chunk=1 << 22):
     """Synthetic PM capture: int16 interleaved I,Q of
@@ -79,13 +92,50 @@ def iq_capture(seed, samprate, seconds, fc_hz=12345.678, beta=1.1, symrate=ACTUA
     out = np.empty(2 * n, dtype=np.int16)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
-        i = np.arange(s, e, dtype=np.float64)
-        ph = i * (symrate / samprate)
-        k = ph.astype(np.int64)
-        m = np.where(ph - k < 0.5, -1.0, 1.0) * sy[k]
-        th = np.mod(i * (2 * np.pi * fc_hz / samprate), 2 * np.pi) + phi0 + beta * m
-        x = amp * np.cos(th) + rng.normal(0, sigma, e - s)
-        y = amp * np.sin(th) + rng.normal(0, sigma, e - s)
-        out[2 * s:2 * e:2] = np.clip(np.rint(x), -32767, 32767).astype(np.int16)
-        out[2 * s + 1:2 * e:2] = np.clip(np.rint(y), -32767, 32767).astype(np.int16)
+        _iq_range(sy, s, e, samprate, fc_hz, beta, symrate, amp, sigma, phi0, rng, out[2 * s:2 * e])
+    return out, bits
+
+
+_SHARED_OUT = None          # the capture being filled (anonymous shared mapping, inherited by the forked workers)
+
+
+def _iq_piece(args):
+    seed, j, s, e, sy, samprate, fc_hz, beta, symrate, amp, sigma, phi0 = args
+    _iq_range(sy, s, e, samprate, fc_hz, beta, symrate, amp, sigma, phi0, np.random.default_rng([seed, j]),
+              _SHARED_OUT[2 * s:2 * e])
+    return j
+
+
+def iq_capture_parallel(seed, samprate, nsamples, workers=8, piece=1 << 22, fc_hz=12345.678, beta=1.1, symrate=ACTUALCLOCK,
+                        cn0_dbhz=45.0):
+    """The same signal model for LONG captures (configs[4]: 64 blocks of 2^23 samples at 10 MS/s = 2.1 GB): carrier and
+    telemetry are functions of the absolute sample index, the noise of piece j comes from its own generator
+    default_rng([seed, j]), so the pieces can be made by `workers` forked processes in any order -- they write straight
+    into one shared anonymous mapping -- and the capture does not depend on how many there are.  amp as
+    iq_capture(amp=None).  Returns (iq int16[2 nsamples], sent bits)."""
+    global _SHARED_OUT
+    import mmap
+    amp = 6000.0 / np.sqrt(samprate / (2.0 * 10 ** (cn0_dbhz / 10.0)))
+    seconds = nsamples / samprate
+    nsym = int(seconds * symrate) + 4
+    bits = telemetry_bits(seed, nsym // 2 + 2)
+    sy = encode_bits(bits)[:nsym].astype(np.int8) * 2 - 1
+    phi0 = np.random.default_rng(seed + 7).random() * 2 * np.pi
+    sigma = amp * np.sqrt(samprate / (2.0 * 10 ** (cn0_dbhz / 10.0)))
+    jobs = [(seed, j, s, min(nsamples, s + piece), sy, samprate, fc_hz, beta, symrate, amp, sigma, phi0)
+            for j, s in enumerate(range(0, nsamples, piece))]
+    buf = mmap.mmap(-1, 4 * nsamples)                  # MAP_SHARED | MAP_ANONYMOUS
+    _SHARED_OUT = np.frombuffer(buf, dtype=np.int16)
+    try:
+        if workers <= 1:
+            for job in jobs:
+                _iq_piece(job)
+        else:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(workers) as pool:
+                for _ in pool.imap_unordered(_iq_piece, jobs, chunksize=1):
+                    pass
+        out = _SHARED_OUT
+    finally:
+        _SHARED_OUT = None
     return out, bits
