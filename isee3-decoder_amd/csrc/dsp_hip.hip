@@ -687,6 +687,9 @@ __global__ __launch_bounds__(256) void k_fft_radix(const double2 *__restrict__ x
 // The first stage reads the int16 (I, Q) pairs themselves (pmdemod.c:209-229, de-chirp :237-243 included): the block is
 // never expanded to doubles in memory.
 #define FT 16
+#ifndef FFT1_ABL
+#define FFT1_ABL 0        // bench builds only, first pass: 1 no global loads, 2 no twiddle walk, 4 no stores, 8 no register DFTs
+#endif
 template <int R> __device__ __forceinline__ void dft_regs(double2 (&a)[R]) {     // radix-2 DIF network; a[brev(k)] = X[k]
 #pragma unroll
   for (int span = R / 2; span >= 1; span >>= 1) {
@@ -753,12 +756,13 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
 #pragma unroll
     for (int b = 0; b < R1; b++) {
       const int i = t + (r + R2 * b) * stride;
-      if constexpr (SRC == SRC_IQ) v[b] = iq_sample(iq, lo, i, flip);
+      if constexpr (FIRST && (FFT1_ABL & 1)) v[b] = make_double2((double)(i & 1023), (double)(i >> 10));
+      else if constexpr (SRC == SRC_IQ) v[b] = iq_sample(iq, lo, i, flip);
       else if constexpr (SRC == SRC_REAL16) v[b] = make_double2(i < flip ? (double)reinterpret_cast<const int16_t *>(iq)[i] : 0.0, 0.0);   // flip = nvalid
       else if constexpr (SRC == SRC_CONJPROD) { const double2 p = cmul(x[i], lo[i]); v[b] = make_double2(p.x, -p.y); }
       else v[b] = x[i];
     }
-    dft_regs<R1>(v);
+    if constexpr (!(FIRST && (FFT1_ABL & 8))) dft_regs<R1>(v);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) {
       double2 val = v[brev(k1, lg2c(R1))];
@@ -773,7 +777,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     double2 u[R2];
 #pragma unroll
     for (int a = 0; a < R2; a++) u[a] = Z[(a * R1 + r) * FTC + c];
-    dft_regs<R2>(u);
+    if constexpr (!(FIRST && (FFT1_ABL & 8))) dft_regs<R2>(u);
     const int q = t & (s - 1), ps = t - q;
     double2 *__restrict__ out = y + q + (size_t)R * ps;
     // stage twiddle W_N^(ps k), k = k1 + R1 k2 (ps k < N), from the two-level table W_N^(4096 h) * W_N^l.  In the first
@@ -785,14 +789,14 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
       if (idx >> 12) w = cmul(twA[idx >> 12], w);
       return w;
     };
-    const bool walk = FIRST;                                // first stage <=> s == 1
+    const bool walk = FIRST && !(FFT1_ABL & 2);             // first stage <=> s == 1
     double2 wk = make_double2(1.0, 0.0), wstep = wk;
     if (walk && ps != 0) { wk = tw2((unsigned)ps * (unsigned)r); wstep = tw2((unsigned)ps * (unsigned)R1); }
 #pragma unroll
     for (int k2 = 0; k2 < R2; k2++) {
       const int k = r + R1 * k2;
       double2 val = u[brev(k2, lg2c(R2))];
-      if (ps != 0 && k != 0) {
+      if (ps != 0 && k != 0 && !(FIRST && (FFT1_ABL & 2))) {
         if (walk) val = cmul(val, wk);
         else val = cmul(val, tw2((unsigned)ps * (unsigned)k));
       }
@@ -821,7 +825,11 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     __syncthreads();
     double2 *__restrict__ blk = y + (size_t)R * ((size_t)blockIdx.x * FTC);
 #pragma unroll 4
-    for (int idx = threadIdx.x; idx < FTC * R; idx += TH) blk[idx] = Z[(idx / R) * (R + 1) + (idx % R)];
+    for (int idx = threadIdx.x; idx < FTC * R; idx += TH) {
+      const double2 o = Z[(idx / R) * (R + 1) + (idx % R)];
+      if constexpr (FFT1_ABL & 4) { if (o.x == 1.2345e300) blk[idx] = o; }
+      else blk[idx] = o;
+    }
   }
   if constexpr (PEAK) {
     constexpr int TH = FTC * (R1 > R2 ? R1 : R2), NW = (TH + 63) / 64;
