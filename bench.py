@@ -685,43 +685,51 @@ def main():
         valu = pmc.get("valu_insts_per_wave")
         cyc = pmc.get("valu_cycles_per_inst", 4.2)
         alg = ALG_BYTES_PER_STEP * steps_per_launch
-        roof = {"kernel": kern, "bound": "valu-issue" if valu else "hbm",
-                "avg_launch_ms": round(avg_ms, 6), "launches_timed": launches, "trellis_steps_per_launch": steps_per_launch,
-                "measured_on": "the single-decoder reference pass of this run (one %s at a time on the GPU; HIP events on the "
-                               "decoder's own stream around runs of back-to-back launches)" % kern if a.split > 1 else "the timed steps",
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % psrc,
-                "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "algorithmic_bytes_per_launch": int(alg)}
-        if launches:
-            t = avg_ms * 1e-3
-            roof["algorithmic_GBps"] = round(alg / t / 1e9, 1)
-            roof["algorithmic_x_peak"] = round(alg / t / 1e9 / HBM_PEAK_GBS, 4)
+        peak = N_SIMD * CLOCK_GHZ / cyc
+
+        def fractions(t):
+            """the kernel's roofs at t seconds per launch: VALU issue (the binding one), physical HBM, SURVEY 8(d)'s algorithmic bytes"""
+            f = {"avg_launch_ms": round(t * 1e3, 6), "algorithmic_GBps": round(alg / t / 1e9, 1),
+                 "algorithmic_x_peak": round(alg / t / 1e9 / HBM_PEAK_GBS, 4)}
             if traffic:
-                roof["hbm_physical_GBps"] = round(traffic / t / 1e9, 1)
-                roof["hbm_physical_frac"] = round(traffic / t / 1e9 / HBM_PEAK_GBS, 4)
+                f["hbm"] = {"bound": "hbm", "achieved": round(traffic / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic}
+                f["hbm_physical_GBps"], f["hbm_physical_frac"] = f["hbm"]["achieved"], f["hbm"]["frac"]
             if valu:
-                # wave-level VALU instructions per second, chip-wide, against what 1024 SIMDs can issue for this mix
                 ach = valu * WAVES_PER_LAUNCH / t / 1e9
-                peak = N_SIMD * CLOCK_GHZ / cyc
-                roof.update({"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s (VALU)",
-                             "frac": round(ach / peak, 4), "valu_insts_per_wave": valu, "valu_cycles_per_inst": cyc,
-                             "note": "15 trellis steps share one pass over the path metrics, so the launch is bound by VALU issue, "
-                                     "not by HBM: frac = VALU instructions per wave x 4 waves per SIMD x %.1f cycles per instruction "
-                                     "(measured for this VOP3P / VOP2 mix, profiles/r01_valu_rate.txt) / (launch time x %.1f GHz); "
-                                     "the SURVEY 8(d) algorithmic bytes exceed what is physically moved (algorithmic_x_peak)"
-                                     % (cyc, CLOCK_GHZ)})
-                if single and single.get("split_avg_launch_ms"):
-                    # the headline mode: two decoders' launches side by side; decoder 0's launch period then covers one
-                    # launch of EACH decoder
-                    tp = single["split_avg_launch_ms"] * 1e-3
-                    roof["two_decoders"] = {"launch_pair_ms": single["split_avg_launch_ms"],
-                                            "achieved": round(2 * valu * WAVES_PER_LAUNCH / tp / 1e9, 1),
-                                            "frac": round(2 * valu * WAVES_PER_LAUNCH / tp / 1e9 / peak, 4),
-                                            "hbm_physical_frac": round(2 * traffic / tp / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                                            "what": "the same fractions during the timed split steps (HIP events on decoder 0's "
-                                                    "stream while decoder 1's launches run beside it)"}
+                f.update({"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s (VALU)",
+                          "frac": round(ach / peak, 4)})
             elif traffic:
-                roof.update({"achieved": roof["hbm_physical_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": roof["hbm_physical_frac"]})
+                f.update({"achieved": f["hbm"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f["hbm"]["frac"]})
+            return f
+
+        roof = {"kernel": kern, "bound": "valu-issue" if valu else "hbm", "trellis_steps_per_launch": steps_per_launch,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % psrc,
+                "algorithmic_bytes_per_step": ALG_BYTES_PER_STEP, "algorithmic_bytes_per_launch": int(alg),
+                "valu_insts_per_wave": valu, "valu_cycles_per_inst": cyc,
+                "note": "15 trellis steps share one pass over the path metrics, so a launch is bound by VALU issue, not by HBM: "
+                        "frac = VALU instructions per wave x 4 waves per SIMD x %.1f cycles per instruction (measured for this VOP3P / "
+                        "VOP2 mix, profiles/r01_valu_rate.txt) / (time per launch x %.1f GHz); `hbm` = the same launch against the "
+                        "8 TB/s HBM peak with the bytes it physically moves; the SURVEY 8(d) algorithmic bytes exceed what is "
+                        "moved (algorithmic_x_peak: fusion depth, not efficiency)" % (cyc, CLOCK_GHZ)}
+        lone = fractions(avg_ms * 1e-3) if launches else None
+        if lone:
+            lone.update({"launches_timed": launches,
+                         "measured_on": ("the single-decoder reference pass of this run" if a.split > 1 else "the timed steps") +
+                                        ": one %s at a time on the GPU; HIP events on the decoder's own stream around runs of "
+                                        "back-to-back launches" % kern})
+        if single and single.get("split_avg_launch_ms"):
+            # the timed region: two decoders' launches side by side; decoder 0's launch period covers one launch of EACH
+            # decoder, i.e. two launches complete per period
+            tp = single["split_avg_launch_ms"] * 1e-3
+            roof.update(fractions(tp / 2))
+            roof.update({"launch_pair_ms": single["split_avg_launch_ms"],
+                         "measured_on": "the timed steps: this stream's two decoders run their launch chains side by side (HIP events on "
+                                        "decoder 0's stream; one launch of each decoder per period, avg_launch_ms = period / 2); the lone "
+                                        "launch is under single_decoder",
+                         "single_decoder": lone})
+        elif lone:
+            roof.update(lone)
         res = {
             "metric": "Viterbi K=24 Msymbols/s",
             "value": round(total_syms / dt / 1e6, 4), "unit": "Msymbols/s",

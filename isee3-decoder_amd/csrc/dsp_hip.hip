@@ -236,8 +236,9 @@ __global__ __launch_bounds__(256) void k_slide(const int16_t *__restrict__ in, i
 // symdemod.c:260-335: thread t = timing offset; the energy is accumulated symbol by symbol IN ORDER in double, as the
 // reference's loop does (this is the form that stays exact when sums leave the 2^53 range).  The integrator sums of
 // TS_BATCH symbols are formed first -- their prefix reads are independent, so their latencies overlap -- and then added
-// in order: 460 -> ~100 us per window at 10 MS/s (9 760 offsets x 1 024 symbols).
-#define TS_BATCH 16
+// in order: 460 -> ~100 us per window at 10 MS/s (9 760 offsets x 1 024 symbols) with batches of 16; the kernel is pure load
+// latency (the 1 024 dependent double additions of a thread are ~3 us), so the batch is 64: a quarter of the round trips.
+#define TS_BATCH 64
 __global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__ P, int lo,
                                                    const int *__restrict__ sw, int symbolclocks,
                                                    int nsymbols, int noff, double *__restrict__ energies) {
@@ -248,16 +249,21 @@ __global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__
   int i = 0;
   if (symbolclocks == 1) {
     for (; i + TS_BATCH <= nsymbols; i += TS_BATCH) {
-      long long sy[TS_BATCH];
-      long long a = Pb[sw[2 * i]];
+      // the 2 TS_BATCH + 1 prefix values of the batch: ALL loads are issued before the first use.  Left to itself the
+      // compiler sinks each load next to its subtraction (two loads in flight: 1 024 dependent round trips per thread,
+      // 150 us per window); the empty asm statements pin the order: loads above the memory barrier, values through "+v".
+      long long pv[2 * TS_BATCH + 1];
+#pragma unroll
+      for (int u = 0; u <= 2 * TS_BATCH; u++) pv[u] = Pb[sw[2 * i + u]];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u <= 2 * TS_BATCH; u++) asm volatile("" : "+v"(pv[u]));
 #pragma unroll
       for (int u = 0; u < TS_BATCH; u++) {
-        const long long b = Pb[sw[2 * (i + u) + 1]], c = Pb[sw[2 * (i + u) + 2]];
-        sy[u] = -(b - a) + (c - b);
-        a = c;
+        const long long a = pv[2 * u], b = pv[2 * u + 1], c = pv[2 * u + 2];
+        const long long sym = -(b - a) + (c - b);
+        energy += (double)(sym * sym);
       }
-#pragma unroll
-      for (int u = 0; u < TS_BATCH; u++) energy += (double)(sy[u] * sy[u]);
     }
   }
   int k = 2 * i * symbolclocks;
@@ -289,6 +295,24 @@ __global__ __launch_bounds__(256) void k_timesearch_part(const long long *__rest
   int i0 = blockIdx.y * TS_SLICE, i1 = i0 + TS_SLICE < nsymbols ? i0 + TS_SLICE : nsymbols;
   unsigned long long acc = 0; unsigned bad = 0;
   int k = 2 * i0 * symbolclocks;
+  if (symbolclocks == 1 && i1 - i0 == TS_SLICE) {      // a whole slice: its 2 TS_SLICE + 1 prefix values in flight at once (see k_timesearch)
+    long long pv[2 * TS_SLICE + 1];
+#pragma unroll
+    for (int u = 0; u <= 2 * TS_SLICE; u++) pv[u] = Pb[sw[k + u]];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u <= 2 * TS_SLICE; u++) asm volatile("" : "+v"(pv[u]));
+#pragma unroll
+    for (int u = 0; u < TS_SLICE; u++) {
+      const long long a = pv[2 * u], b = pv[2 * u + 1], c = pv[2 * u + 2];
+      const long long sym = -(b - a) + (c - b);
+      const unsigned long long m = (unsigned long long)(sym < 0 ? -sym : sym);
+      if (m >= (1ull << 26)) bad = 1;
+      acc += m * m;
+      if (acc >= TS_LIMIT) bad = 1;
+    }
+    i0 = i1;
+  }
   for (int i = i0; i < i1; i++) {
     long long sym = 0;
     for (int j = 0; j < symbolclocks; j++, k += 2) {
@@ -753,6 +777,43 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
   const int t = blockIdx.x * FTC + c, stride = N / R;
   if (r < R2) {                                           // ---- step 1, thread (c, a = r)
     double2 v[R1];
+    if constexpr (SRC == SRC_IQ && !(FIRST && (FFT1_ABL & 1))) {
+      // all R1 loads first, then the conversions: written per sample (iq_sample: load, test `lo`, convert) the compiler
+      // waited for every load before issuing the next -- sixteen dependent memory round trips, 45 of the pass's 74 us
+      short2 raw[R1];
+#pragma unroll
+      for (int b = 0; b < R1; b++) raw[b] = iq[t + (r + R2 * b) * stride];
+      if (lo) {                                             // buffer[i] *= conj(lophase), pmdemod.c:237-243
+        double2 l[R1];
+#pragma unroll
+        for (int b = 0; b < R1; b++) l[b] = lo[t + (r + R2 * b) * stride];
+#pragma unroll
+        for (int b = 0; b < R1; b++) {
+          const double x = flip ? (double)raw[b].y : (double)raw[b].x, y = flip ? (double)raw[b].x : (double)raw[b].y;
+          const double pr = l[b].x, pi = -l[b].y;
+          v[b] = make_double2(x * pr - y * pi, x * pi + y * pr);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < R1; b++)
+          v[b] = make_double2(flip ? (double)raw[b].y : (double)raw[b].x, flip ? (double)raw[b].x : (double)raw[b].y);
+      }
+    } else if constexpr (SRC == SRC_CONJPROD) {             // conj(x[i] * v[i]); both operand sets loaded before the first product
+      double2 xa[R1], va[R1];
+#pragma unroll
+      for (int b = 0; b < R1; b++) { xa[b] = x[t + (r + R2 * b) * stride]; va[b] = lo[t + (r + R2 * b) * stride]; }
+#pragma unroll
+      for (int b = 0; b < R1; b++) { const double2 p = cmul(xa[b], va[b]); v[b] = make_double2(p.x, -p.y); }
+    } else if constexpr (SRC == SRC_REAL16) {               // int16 real samples, zero beyond flip = nvalid (icesync.c:151-163)
+      int16_t ra[R1];
+#pragma unroll
+      for (int b = 0; b < R1; b++) {
+        const int i = t + (r + R2 * b) * stride;
+        ra[b] = reinterpret_cast<const int16_t *>(iq)[i < flip ? i : 0];       // always a load (no branch), masked below
+      }
+#pragma unroll
+      for (int b = 0; b < R1; b++) v[b] = make_double2(t + (r + R2 * b) * stride < flip ? (double)ra[b] : 0.0, 0.0);
+    } else
 #pragma unroll
     for (int b = 0; b < R1; b++) {
       const int i = t + (r + R2 * b) * stride;
@@ -784,29 +845,45 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     // stage ps = t differs from lane to lane and every lookup is a 64-address gather: there the thread looks up only
     // W^(ps k1) and the step W^(ps R1) and walks k2 by multiplication (<= 15 products: ~1e-15 relative); later stages
     // have ONE ps per tile, their lookups are broadcasts and stay direct.
-    auto tw2 = [&](unsigned idx) {
-      double2 w = twB[idx & 4095u];
-      if (idx >> 12) w = cmul(twA[idx >> 12], w);
-      return w;
-    };
-    const bool walk = FIRST && !(FFT1_ABL & 2);             // first stage <=> s == 1
-    double2 wk = make_double2(1.0, 0.0), wstep = wk;
-    if (walk && ps != 0) { wk = tw2((unsigned)ps * (unsigned)r); wstep = tw2((unsigned)ps * (unsigned)R1); }
-#pragma unroll
-    for (int k2 = 0; k2 < R2; k2++) {
-      const int k = r + R1 * k2;
-      double2 val = u[brev(k2, lg2c(R2))];
-      if (ps != 0 && k != 0 && !(FIRST && (FFT1_ABL & 2))) {
-        if (walk) val = cmul(val, wk);
-        else val = cmul(val, tw2((unsigned)ps * (unsigned)k));
+    // W_N^idx = twB[idx & 4095] (* twA[idx >> 12] when that is not W^0).  In the first stage both table words of both
+    // lookups are loaded before the first use (four loads in flight instead of four dependent round trips).
+    auto tw2_sel = [&](unsigned idx, double2 wb, double2 wa) { return (idx >> 12) ? cmul(wa, wb) : wb; };
+    if constexpr (FIRST) {
+      const bool walk = !(FFT1_ABL & 2);                    // first stage <=> s == 1
+      double2 wk = make_double2(1.0, 0.0), wstep = wk;
+      if (walk) {
+        const unsigned i1 = (unsigned)ps * (unsigned)r, i2 = (unsigned)ps * (unsigned)R1;
+        const double2 b1 = twB[i1 & 4095u], a1 = twA[i1 >> 12], b2 = twB[i2 & 4095u], a2 = twA[i2 >> 12];
+        if (ps != 0) { wk = tw2_sel(i1, b1, a1); wstep = tw2_sel(i2, b2, a2); }
       }
-      if (walk) wk = cmul(wk, wstep);
-      if constexpr (FIRST) u_first[k2] = val;               // parked: leaves through the LDS transpose below
-      else out[(size_t)k * s] = val;
-      if constexpr (PEAK) {
-        const int i = q + R * ps + k * s;                   // the bin this value is (the last pass: N fits an int)
-        const double e = val.x * val.x + val.y * val.y;
-        if (i >= pfirst && i < plast && peak_better(e, i, be, bi)) { be = e; bi = i; }
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) {
+        const int k = r + R1 * k2;
+        double2 val = u[brev(k2, lg2c(R2))];
+        if (walk && ps != 0 && k != 0) val = cmul(val, wk);
+        if (walk) wk = cmul(wk, wstep);
+        u_first[k2] = val;                                  // parked: leaves through the LDS transpose below
+      }
+    } else {
+      // later stages: ONE ps per tile, so a lookup is a broadcast that hits the L1 / L2; looked up value by value.  (Issuing
+      // all 2 R2 table loads first was measured too: 150 -> 217 VGPRs at R = 256 and the passes got SLOWER beside a running
+      // decoder, 72 -> 78 and 60 -> 78 us at N = 2^23.)
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) {
+        const int k = r + R1 * k2;
+        double2 val = u[brev(k2, lg2c(R2))];
+        if (ps != 0 && k != 0) {
+          const unsigned idx = (unsigned)ps * (unsigned)k;
+          double2 w = twB[idx & 4095u];
+          if (idx >> 12) w = cmul(twA[idx >> 12], w);
+          val = cmul(val, w);
+        }
+        out[(size_t)k * s] = val;
+        if constexpr (PEAK) {
+          const int i = q + R * ps + k * s;                 // the bin this value is (the last pass: N fits an int)
+          const double e = val.x * val.x + val.y * val.y;
+          if (i >= pfirst && i < plast && peak_better(e, i, be, bi)) { be = e; bi = i; }
+        }
       }
     }
   }

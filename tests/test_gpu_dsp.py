@@ -414,6 +414,30 @@ def test_config2_full_size_chain_equals_oracle_chain(pkg):
     assert got[-1100:-100].decode() in s
 
 
+@pytest.mark.slow
+def test_config3_eight_captures_on_one_gpu(pkg, monkeypatch):
+    """BASELINE configs[3]: the eight independent captures bench.py deals one per GPU (seeds 3 .. 10, 60 s x 250 kS/s each),
+    here one after the other on the one GPU of the box -- the N > 1 form needs the node and differs only in which rank
+    runs which seed (tests/test_dist_harness.py).  Every capture: the chain with the capture in HBM, in both Viterbi-stage
+    modes, gives the same bits; ~30 000 of them; and a 1 000-bit run from the end is found in the telemetry that was sent.
+    Seed 3 is the capture test_config2_full_size_chain_equals_oracle_chain pins to the oracle chain bit for bit."""
+    from importlib import import_module
+    synth = import_module("isee3_decoder_amd.synth")
+    fs = 250000.0
+    for seed in range(3, 11):
+        iq, sent = synth.iq_capture(seed, fs, 60.0, amp=None)
+        d_iq = pkg.DeviceBuffer.from_numpy(iq)
+        got = {}
+        for mode in ("progressive", "block"):
+            monkeypatch.setenv("ISEE3_CHAIN_MODE", mode)
+            got[mode] = pkg.run_chain(d_iq, samprate=fs, binsize=1.0, symrate="1024", decode_delay=200)
+        d_iq.free()
+        assert got["progressive"] == got["block"], "seed %d: the two Viterbi-stage modes differ" % seed
+        assert 29500 < len(got["block"]) < 31000, (seed, len(got["block"]))
+        assert got["block"][-1100:-100].decode() in "".join(map(str, sent)), "seed %d: decoded run not in the sent stream" % seed
+    pkg.release_chain_objects()
+
+
 def test_config4_form_64_overlapped_segments(pkg):
     """BASELINE configs[4] form at a shortened capture: ONE capture cut into 64 block-aligned segments, each extended to
     the left by a 7-block warm-up, decoded independently (two chains at a time on this GPU) and stitched: all seams
