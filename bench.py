@@ -202,7 +202,7 @@ def _chain_cpu_legs(orc, part, nsamp, fs, binsize):
 def pmc_constants(kern):
     """PMC passes cannot share a run with the timing: the per-launch HBM bytes and VALU instruction count of the kernel
     are committed constants (profiles/), refreshed whenever the kernel changes."""
-    for tname in ("r02_pmc_lds15.json", "r01c_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r03_pmc_lds15.json", "r02_pmc_lds15.json", "r01c_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
