@@ -1,27 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the ISEE-3 receive-chain hot path on MI355X.
 
-BASELINE.json's metric has two halves; the ONE JSON line rank 0 prints carries both:
+BASELINE.json's metric has two halves; the ONE JSON line rank 0 prints carries both, and the stress configuration:
 
   top level  "Viterbi K=24 Msymbols/s" on BASELINE configs[1]: one 1e7-symbol synthetic soft-symbol stream per GPU,
              decoded with the semantics of `vdecode -d 200` (one trellis step + decodebit(200,0) per bit).  A "step" =
-             one full pass of that stream (init + 5e6 trellis steps + 5e6 tracebacks).  Symbols are resident in HBM
-             before the timed region starts and the decoded bits stay there (the 10 MB H2D / 5 MB D2H, ~1 ms of a
-             ~4 s step, are excluded -- stated in config.residency).
-  "chain"    "end-to-end IQ Msamples/s" on BASELINE configs[2]: 60 s x 250 kS/s synthetic int16 IQ per GPU through
+             one full pass of that stream (init + 5e6 trellis steps + 5e6 tracebacks) on two decoders (verified split).
+             `value`: symbols resident in HBM when the timed region starts, bits left there; config.host_buffers: one
+             more step from host symbols to host bits (SURVEY 8(d) config 2's region, PCIe inclusive).
+  "frames"   BASELINE configs[0]'s shape: 50 frames x 1 000 bits as one v224hip_decode_frames batch.
+  "chain"    "end-to-end IQ Msamples/s" on BASELINE configs[2] / [3]: 60 s x 250 kS/s synthetic int16 IQ per GPU through
              pmdemod | symdemod | vdecode in one process (libisee3chain.so), capture resident in HBM
              (isee3_chain_run_dev); the rate with the capture in host memory (PCIe included) rides along.
+  "stress"   BASELINE configs[4]: 10 MS/s, 1 Hz bins (N = 2^23), ONE 64-block capture cut into 64 overlapped segments dealt
+             to the ranks, stitched on rank 0 with every seam verified (strong scaling).
 
-N > 1 (torch.distributed.run, one rank per GPU, RCCL only for the barrier / MAX / SUM): every rank works on its own
-independent stream and capture -- segments shard one per GPU, no collective in the data path -> weak scaling.
+N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process
+(before anything here touches a device); one rank per GPU, RCCL only for the barrier / MAX / SUM / the gather of decoded
+bits: every rank works on its own independent stream and capture -- segments shard one per GPU, no collective in the
+data path -> weak scaling (the stress record: strong).
 
-  roofline      the dominant kernel k_acs_lds15.  It is VALU-issue bound (15 trellis steps share ONE pass over the
-                path metrics), so `frac` = VALU issue time / launch time <= 1; `hbm_physical_frac` = PMC bytes / launch
-                time / 8 TB/s; the SURVEY 8(d) algorithmic figure (34 603 008 B per trellis step) is kept as
-                `algorithmic_x_peak`.  Launch time: HIP events on the decoder's own stream, live in this run.
+  roofline      the dominant kernel k_acs_lds15 over the timed region (two decoders side by side) with the lone launch
+                under single_decoder.  It is VALU-issue bound (15 trellis steps share ONE pass over the path metrics):
+                `frac` = VALU issue time / time per launch <= 1; `hbm` = PMC bytes per launch / time per launch against
+                8 TB/s; the SURVEY 8(d) algorithmic figure (34 603 008 B per trellis step) is `algorithmic_x_peak`.
+                Time per launch: HIP events on decoder 0's own stream, live in this run.  chain.roofline / stress.roofline:
+                physical HBM bytes of all the chain's kernels (committed PMC passes) / step time against 8 TB/s.
   cpu_baseline  the reference's SSE2 decoder (oracle/_ref, built from /root/reference in the build container) on ONE
-                host core, bounded sample; chain.cpu_baseline: oracle pmdemod -> reference symdemod -> reference
-                vdecode (SSE2) on the first seconds of the same capture.
+                pinned host core, bounded sample, with the host's CPU model / nproc / build flags; chain.cpu_baseline:
+                oracle pmdemod -> reference symdemod -> reference vdecode (SSE2) on the first seconds of the same capture.
 """
 import argparse
 import importlib.util
@@ -482,8 +489,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--symbols", type=int, default=10_000_000)
     ap.add_argument("--delay", type=int, default=200)
-    ap.add_argument("--engine", type=int, default=-1)
-    ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--segments-per-gpu", type=int, default=1,
                     help="independent streams decoded concurrently on each GPU (own HIP streams)")
@@ -562,15 +567,13 @@ def main():
     nbits = a.symbols // 2
     nseg = world * a.segments_per_gpu
     mine = harness.shard_segments(nseg, world, rank)      # segment g -> rank g mod world
-    eng = a.engine if a.engine >= 0 else int(os.environ.get("V224HIP_ENGINE", "3"))
-    own_tb = os.environ.get("V224HIP_TB_STREAM", "0") not in ("", "0")
-    chunk = a.chunk or (1024 if eng == 2 else (1020 if own_tb else 2040))           # 1020 = 68 x 15 = 204 x 5
+    chunk = a.chunk or 2040                               # 136 passes of 15 steps; tracebacks in the decoder's own stream
     segs = []
     for g in mine:
         syms, bits, noise_mask = synth.coded_stream(1000 + g, nbits, 3.0, 24.0, 1.0)
         decs = []
         for _ in range(max(1, a.split)):
-            dec = pkg.Viterbi224(a.delay + (2 if own_tb or eng == 2 else 1) * chunk, a.engine, a.k)
+            dec = pkg.Viterbi224(a.delay + chunk, 3)           # the 15-step LDS engine (the remainder engines are test subjects)
             dec.set_option("chunk", chunk)
             decs.append(dec)
         segs.append(dict(dec=decs[0], decs=decs, d_syms=pkg.DeviceBuffer.from_numpy(syms), d_out=pkg.DeviceBuffer(nbits),
@@ -664,7 +667,7 @@ def main():
             d.close()
         sg["d_syms"].free(); sg["d_out"].free()
 
-    frames = frames_record(pkg, synth) if not a.no_frames and eng == 3 else None
+    frames = frames_record(pkg, synth) if not a.no_frames else None
     chain = None
     if not a.no_chain:
         chain = chain_record(a, ctx, a.chain_seconds, a.chain_rate, a.chain_bin, a.chain_steps or a.steps, max(1, a.warmup),
@@ -679,7 +682,7 @@ def main():
         total_syms = 2 * nbits * nseg * a.steps
         avg_ms = ms / launches if launches else float("nan")
         steps_per_launch = steps_timed / launches if launches else 0
-        kern = {0: "k_acs_simple", 1: "k_acs_fused", 2: "k_acs_lds8", 3: "k_acs_lds15"}[eng]
+        kern = "k_acs_lds15"
         pmc, psrc = pmc_constants(kern)
         traffic = pmc.get("hbm_bytes_per_launch")
         valu = pmc.get("valu_insts_per_wave")
@@ -746,8 +749,7 @@ def main():
                                         "what": "SURVEY 8(d) config 2's region: %.1f MB of symbols H2D (pageable numpy array, "
                                                 "blocking copy), the whole decode, %.1f MB of bits D2H into a host array -- "
                                                 "PCIe inclusive, never the headline" % (2 * nbits / 1e6, nbits / 1e6)},
-                       "engine": {0: "simple", 1: "fused", 2: "lds8", 3: "lds15"}[eng],
-                       "steps_per_launch": {0: 1, 1: a.k or int(os.environ.get("V224HIP_K", "5")), 2: 8, 3: 15}[eng],
+                       "engine": "lds15", "steps_per_launch": 15,
                        "chunk_bits": chunk,
                        "segments_per_gpu": a.segments_per_gpu, "parallelism": "segments x%d" % nseg,
                        "decoders_per_stream": a.split,
