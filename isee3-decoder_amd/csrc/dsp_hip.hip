@@ -1158,7 +1158,12 @@ struct PeakAsk { int first, last; PeakRec *part; int nparts; };     // nparts: s
 template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT>
 static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FTC * (R1 > R2 ? R1 : R2);
-  const size_t lds = sizeof(double2) * (FIRST ? R + 1 : R) * FTC;      // a first stage re-uses the tile as its padded output image
+  size_t lds = sizeof(double2) * (FIRST ? R + 1 : R) * FTC;            // a first stage re-uses the tile as its padded output image
+  // ISEE3DSP_FFT_LDS_KB=n: every pass ASKS for n KiB of LDS (it uses what it needs).  With 88 exactly one FFT workgroup fits a
+  // CU and 72 KiB stay free: a Viterbi workgroup (68.6 KiB) always finds room beside it, whereas two 64 KiB FFT workgroups
+  // on a CU make the 256-workgroup ACS launch wait for one of them to finish
+  static const size_t lds_floor = getenv("ISEE3DSP_FFT_LDS_KB") ? (size_t)atoi(getenv("ISEE3DSP_FFT_LDS_KB")) * 1024u : 0u;
+  if (lds < lds_floor && lds_floor <= 160u * 1024u) lds = lds_floor;
   // 64 KiB of dynamic LDS at R = 256: raised once per device and instantiation (bit d = done on device d; transforms run
   // from several host threads, a doubled call is harmless, the flag itself is atomic)
   static std::atomic<unsigned long long> attr_set{0};
