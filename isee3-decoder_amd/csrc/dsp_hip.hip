@@ -1186,6 +1186,9 @@ template <int SRC, bool FIRST, bool PEAK = false>
 static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
   // a first pass over int16 samples (4 or 2 bytes each) takes 32 columns per workgroup where its tile still fits 64 KiB of LDS
   constexpr bool NARROW = FIRST && (SRC == SRC_IQ || SRC == SRC_REAL16);
+  // (tiles of at most 32 KiB -- 8 columns for the later radix-256 passes, radix 128 x 16 columns first -- so that workgroups are
+  // short-lived and several fit beside a Viterbi workgroup were measured in the 10 MS/s chain: 36.0-37.2 ms against 34.4-35.8,
+  // the decoder no further along when the front end ends; profiles/r03p_chain10M_fft_small_tiles.txt)
   switch (lg) {
   case 5: return launch_pass<5, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
   case 6: return launch_pass<6, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
