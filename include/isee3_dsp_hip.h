@@ -72,6 +72,16 @@ int symd_timesearch(void *h, int lo, const int *sw, int symbolclocks, int nsymbo
 int symd_demod(void *h, const int *edges, int symbolclocks, int nsymbols, double gain,
                uint8_t *out, int out_is_dev, double *energy_sum);
 
+/* One whole window of symdemod.c:127-131,190-192 (no -t) with ONE synchronisation: timing search over offsets
+ * firstsample + first_off + t (t < noff; sw as symd_timesearch), its first maximum, and trial_demod with gain
+ * 100 / sqrt(maxenergy) -- the host SPECULATES the boundary tables: edges holds nspec tables of 2*symbolclocks*nsymbols + 1
+ * absolute boundaries, table j being trial_demod's recurrence (symdemod.c:212-236) started at firstsample + spec_lo + j.
+ * Returns 0: out[nsymbols], *symphase (the timing adjustment that won) and *maxenergy (per symbol) are what the
+ * step-by-step calls give; 1: not decidable this way (adjustment outside the tables, sums outside the exactly representable
+ * range, a differently rounded gain) -- nothing was produced, take symd_timesearch / symd_demod for this window; -1: error. */
+int symd_window(void *h, int firstsample, const int *sw, int symbolclocks, int nsymbols, int first_off, int noff,
+                const int *edges, int spec_lo, int nspec, uint8_t *out, int *symphase, double *maxenergy);
+
 /* ------------------------------------------------------------------ pmdemod (pmdemod.c) ------ */
 typedef struct {
   int    peak;            /* argmax |X|^2 over [firstbin,lastbin), last maximum wins (pmdemod.c:288-298) */

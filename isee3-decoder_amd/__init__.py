@@ -265,7 +265,7 @@ class Viterbi224:
 DSP_SYMBOLS = [
     "isee3dsp_last_error", "isee3dsp_set_device", "isee3dsp_share_stream", "isee3dsp_dev_alloc", "isee3dsp_dev_free", "isee3dsp_h2d", "isee3dsp_d2h",
     "symd_create", "symd_destroy", "symd_load", "symd_timesearch", "symd_demod",
-    "symd_store_reset", "symd_store_slide", "symd_store_put", "symd_store_scan",
+    "symd_store_reset", "symd_store_slide", "symd_store_put", "symd_store_scan", "symd_window",
     "pmd_create", "pmd_destroy", "pmd_set_dechirp", "pmd_load", "pmd_fft_peak", "pmd_mix_quantise",
     "pmd_get_spectrum",
     "isync_create", "isync_destroy", "isync_set_vector", "isync_search",

@@ -114,6 +114,8 @@ static int sy_demod(void *h, const int *e, int sc, int ns, double g, uint8_t *o,
 static int sy_slide(void *h, int slide, int n) { TIMED(symd_store_slide(PMH(h), slide, n)); }
 static int sy_put(void *h, int at, const int16_t *src, int n, int dev) { TIMED(symd_store_put(PMH(h), at, src, n, dev)); }
 static int sy_scan(void *h, int n) { TIMED(symd_store_scan(PMH(h), n)); }
+static int sy_window(void *h, int fs, const int *sw, int sc, int ns, int fo, int noff, const int *ed, int lo, int nspec,
+                     uint8_t *out, int *ph, double *me) { TIMED(symd_window(PMH(h), fs, sw, sc, ns, fo, noff, ed, lo, nspec, out, ph, me)); }
 static void sy_destroy(void *p) {
   dsp_ctx *c = p;
   if (!c) return;
@@ -414,7 +416,8 @@ static void *pm_thread(void *p) {
 }
 static void *sy_thread(void *p) {
   sy_arg *a = p;
-  symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy, sy_slide, sy_put, sy_scan };
+  symdemod_engine e = { sy_create, sy_load, sy_ts, sy_demod, sy_destroy, sy_slide, sy_put, sy_scan, sy_window };
+  if (getenv("SYMDEMOD_STEPWISE") && atoi(getenv("SYMDEMOD_STEPWISE"))) e.window = NULL;
   /* this thread writes into the pipe the Viterbi stage reads: should that stage ever go away first, the write must fail
    * with EPIPE (a stage error) and not raise SIGPIPE, whose default action would end the HOST program */
   sigset_t sp;

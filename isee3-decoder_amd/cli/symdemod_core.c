@@ -99,6 +99,33 @@ static int timesearch(ctx_t *c, int *symphase, int firstsample, double symbolsam
   return 0;
 }
 
+/* A whole window through engine->window (symdemod_core.h): the relative switch points of the search, and the absolute
+ * boundaries of the final demodulation for the timing adjustments -SPEC_HALF .. +SPEC_HALF -- each table the reference's own
+ * recurrence (symdemod.c:212-236) started at firstsample + adjustment, as trial() forms it.  The adjustment is a sample
+ * or two in a tracking loop; anything else comes back as 1 and the caller takes the step-by-step path. */
+#define SPEC_HALF 2
+static int window_fused(ctx_t *c, int firstsample, double symbolsamples, int nsymbols, uint8_t *out, int *symphase,
+                        double *maxenergy_per_symbol) {
+  const int nsw = 2 * c->symbolclocks * nsymbols + 1, nspec = 2 * SPEC_HALF + 1;
+  if (need_idx(c, nsw * (1 + nspec))) return -1;
+  const double halfclock = (0.5 / c->symbolclocks) * symbolsamples;
+  int *sw = c->idx, *tab = c->idx + nsw;
+  double scount = halfclock;
+  sw[0] = 0;
+  for (int k = 1; k < nsw; k++) { sw[k] = (int)nearbyint(scount); scount += halfclock; }
+  int first_off = (int)(-symbolsamples / 2), noff = 0;
+  for (int o = first_off; o < symbolsamples / 2; o++) noff++;
+  for (int j = 0; j < nspec; j++) {
+    const int fs = firstsample + j - SPEC_HALF;
+    int *e = tab + (size_t)j * nsw;
+    scount = fs + halfclock;
+    e[0] = fs;
+    for (int k = 1; k < nsw; k++) { e[k] = (int)nearbyint(scount); scount += halfclock; }
+  }
+  return c->e->window(c->h, firstsample, sw, c->symbolclocks, nsymbols, first_off, noff, tab, -SPEC_HALF, nspec, out, symphase,
+                      maxenergy_per_symbol);
+}
+
 static long fd_reader(void *ctx, void *buf, unsigned long nbytes) { return (long)read(*(int *)ctx, buf, nbytes); }
 int symdemod_run(const symdemod_opts *o, const symdemod_engine *e, int fd_in, FILE *out, FILE *err) {
   return symdemod_run_rd(o, e, fd_reader, &fd_in, out, err);
@@ -165,9 +192,14 @@ static int run(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader
        little past nsamples near end of input and reads whatever the buffer holds there */
     if (store ? e->store_scan(c.h, fullwater + slack) != 0 : e->load(c.h, samples, fullwater + slack) != 0) goto done;
 
-    int symphase = 0;
+    int symphase = 0, fused = 0;
     double maxenergy = 0;
-    if (timesearch(&c, &symphase, firstsample, Symbolsamples, Symbolsamples, nsymbols, &maxenergy)) goto done;
+    if (e->window && !o->clocktrack) {               /* search + first maximum + final demodulation in one engine call */
+      const int wr = window_fused(&c, firstsample, Symbolsamples, nsymbols, obuf, &symphase, &maxenergy);
+      if (wr < 0) goto done;
+      fused = wr == 0;
+    }
+    if (!fused && timesearch(&c, &symphase, firstsample, Symbolsamples, Symbolsamples, nsymbols, &maxenergy)) goto done;
     firstsample += symphase;
 
     if (o->clocktrack) {                             /* symdemod.c:133-174 */
@@ -200,7 +232,7 @@ static int run(const symdemod_opts *o, const symdemod_engine *e, symdemod_reader
               Symbolsamples, symphase, 10 * log10(maxenergy));
 
     double gain = 100. / sqrt(maxenergy);            /* symdemod.c:190 */
-    if (trial(&c, firstsample, Symbolsamples, nsymbols, gain, obuf, NULL)) goto done;
+    if (!fused && trial(&c, firstsample, Symbolsamples, nsymbols, gain, obuf, NULL)) goto done;
     fwrite(obuf, 1, (size_t)nsymbols, out);
     firstsample = (int)(firstsample + nsymbols * Symbolsamples);
     total_symbols += nsymbols;

@@ -32,6 +32,11 @@ typedef struct {
   int   (*store_slide)(void *h, int slide, int nsamples);
   int   (*store_put)(void *h, int at, const int16_t *src, int n, int src_is_dev);
   int   (*store_scan)(void *h, int n);
+  /* optional: a whole window (search, first maximum, final demodulation) behind ONE synchronisation, the boundary tables
+     of the final demodulation speculated by the caller for the timing adjustments spec_lo .. spec_lo + nspec - 1
+     (include/isee3_dsp_hip.h: symd_window).  0 done, 1 take the step-by-step calls for this window, -1 error. */
+  int   (*window)(void *h, int firstsample, const int *sw, int symbolclocks, int nsymbols, int first_off, int noff,
+                  const int *edges, int spec_lo, int nspec, uint8_t *out, int *symphase, double *maxenergy);
 } symdemod_engine;
 
 void symdemod_default_opts(symdemod_opts *o);

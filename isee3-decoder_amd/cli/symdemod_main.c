@@ -16,13 +16,18 @@ static int eng_demod(void *h, const int *edges, int sc, int ns, double gain, uin
   return symd_demod(h, edges, sc, ns, gain, out, 0, esum);
 }
 static void eng_destroy(void *h) { symd_destroy(h); }
+static int eng_window(void *h, int fs, const int *sw, int sc, int ns, int fo, int noff, const int *ed, int lo, int nspec,
+                      uint8_t *out, int *ph, double *me) {
+  return symd_window(h, fs, sw, sc, ns, fo, noff, ed, lo, nspec, out, ph, me);
+}
 
 int main(int argc, char **argv) {
   symdemod_opts o;
   const char *lang = getenv("LANG");
   setlocale(LC_ALL, lang ? lang : "en_US.utf8");
   symdemod_parse_args(&o, argc, argv);
-  symdemod_engine e = { eng_create, eng_load, eng_ts, eng_demod, eng_destroy };
+  symdemod_engine e = { eng_create, eng_load, eng_ts, eng_demod, eng_destroy, NULL, NULL, NULL, eng_window };
+  if (getenv("SYMDEMOD_STEPWISE") && atoi(getenv("SYMDEMOD_STEPWISE"))) e.window = NULL;     /* the two-round-trip path */
   if (symdemod_run(&o, &e, 0, stdout, stderr) != 0) {
     fprintf(stderr, "%s: engine failed: %s\n", o.argv0, isee3dsp_last_error());
     return 2;

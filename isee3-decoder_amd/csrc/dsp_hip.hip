@@ -586,6 +586,125 @@ fail:
   return -1;
 }
 
+// ---- one whole window in one go (symd_window) ------------------------------------------------------------------------
+// symdemod.c:127-131,190-192 without -t: timing search, its first maximum, final demodulation with gain 100 / sqrt(maxenergy).
+// Taken step by step (symd_timesearch, the host's arg-max and boundary recurrence, symd_demod) a window costs two host round
+// trips; at 250 kS/s those, not the kernels, are its 160 us, and the Viterbi stage waits for the symbols.  Here the host
+// SPECULATES: it hands over the boundary tables of trial_demod for a few timing adjustments around zero (each table is the
+// reference's own FP recurrence started at firstsample + adjustment, computed while the GPU scans), the arg-max stays on
+// the device, the demodulation picks the table of the adjustment that won -- one synchronisation.  An adjustment
+// outside the tables, a gain the device rounds differently from the host, or sums outside the exact range make the call
+// return 1 and change nothing: the caller then takes the step-by-step calls for that window.
+struct WinHdr { int bi; int miss; double best; double gain; unsigned inexact; unsigned pad; };
+__global__ __launch_bounds__(256) void k_ts_argmax(const double *__restrict__ en, int noff, WinHdr *__restrict__ hdr) {
+  __shared__ double wv[256]; __shared__ int wi[256];
+  double be = 0; int bi = -1;
+  for (int t = threadIdx.x; t < noff; t += 256) {                    // ascending t per thread: strict '>' keeps the first maximum
+    const double e = en[t];
+    if (bi < 0 || e > be) { be = e; bi = t; }
+  }
+  wv[threadIdx.x] = be; wi[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double oe = wv[threadIdx.x + o]; const int oi = wi[threadIdx.x + o];
+      const double me = wv[threadIdx.x]; const int mi = wi[threadIdx.x];
+      if (oi >= 0 && (mi < 0 || oe > me || (oe == me && oi < mi))) { wv[threadIdx.x] = oe; wi[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { hdr->bi = wi[0]; hdr->best = wv[0]; hdr->miss = 0; }
+}
+__global__ __launch_bounds__(256) void k_window_demod(const long long *__restrict__ P, const int *__restrict__ tables, int ne,
+                                                      int first_off, int spec_lo, int nspec, const unsigned char *__restrict__ table_ok,
+                                                      int symbolclocks, int nsymbols, const WinHdr *__restrict__ hdr,
+                                                      const unsigned *__restrict__ inexact, uint8_t *__restrict__ out,
+                                                      WinHdr *__restrict__ host_hdr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int bi = hdr->bi, j = bi + first_off - spec_lo;
+  const double best = hdr->best;
+  const double maxenergy = best / (double)nsymbols;                  // symdemod.c:333
+  const double gain = 100. / sqrt(maxenergy);                        // :190
+  const bool miss = j < 0 || j >= nspec || !table_ok[j < 0 || j >= nspec ? 0 : j];
+  if (i == 0) { host_hdr->bi = bi; host_hdr->best = best; host_hdr->gain = gain; host_hdr->miss = miss ? 1 : 0;
+                host_hdr->inexact = inexact ? *inexact : 0u; }
+  if (miss || i >= nsymbols) return;
+  const int *__restrict__ edges = tables + (size_t)j * ne;
+  long long integ = 0;
+  int k = 2 * i * symbolclocks;
+  for (int c = 0; c < symbolclocks; c++, k += 2) {
+    const long long a = P[edges[k]], b = P[edges[k + 1]], d = P[edges[k + 2]];
+    integ += -(b - a) + (d - b);
+  }
+  double scaled = gain * (double)integ + 128;                        // :240-251 (not fused: -ffp-contract=off)
+  if (scaled > 255) scaled = 255; else if (scaled < 0) scaled = 0;
+  out[i] = (unsigned char)scaled;
+}
+extern "C" int symd_window(void *p, int firstsample, const int *sw, int symbolclocks, int nsymbols, int first_off, int noff,
+                           const int *edges, int spec_lo, int nspec, uint8_t *out, int *symphase, double *maxenergy) {
+  Symd *h = (Symd *)p;
+  if (!h || !sw || !edges || !out || nspec < 1 || nspec > 16 || noff < 1 || nsymbols < 1) {
+    snprintf(g_err, sizeof g_err, "symd_window: bad argument");
+    return -1;
+  }
+  {
+    const int nsw = 2 * symbolclocks * nsymbols + 1, lo = firstsample + first_off;
+    if (lo < 0 || lo + noff - 1 + sw[nsw - 1] > h->n) return 1;     // the step-by-step call reports it
+    CHK(hipSetDevice(h->dev));
+    const size_t tab_ints = (size_t)nsw * (size_t)(1 + nspec);
+    if (grow(&h->d_idx, &h->idx_cap, sizeof(int) * tab_ints + 64) || pin_grow(&h->pin_idx, sizeof(int) * tab_ints + 64) ||
+        grow(&h->d_e, &h->e_cap, sizeof(double) * (size_t)noff + sizeof(WinHdr)) || pin_grow(&h->pin_out, (size_t)nsymbols) ||
+        pin_grow(&h->pin_hdr, 256)) {
+      snprintf(g_err, sizeof g_err, "symd_window: allocation failed");
+      return -1;
+    }
+    // staging: [sw | nspec edge tables | nspec validity bytes]
+    int *st = (int *)h->pin_idx.h;
+    memcpy(st, sw, sizeof(int) * (size_t)nsw);
+    memcpy(st + nsw, edges, sizeof(int) * (size_t)nsw * (size_t)nspec);
+    unsigned char *ok = (unsigned char *)(st + tab_ints);
+    int any = 0;
+    for (int j = 0; j < nspec; j++) { const int *e = edges + (size_t)j * nsw; ok[j] = e[0] >= 0 && e[nsw - 1] <= h->n; any |= ok[j]; }
+    if (!any) return 1;
+    CHK(hipMemcpyAsync(h->d_idx, st, sizeof(int) * tab_ints + 64, hipMemcpyHostToDevice, h->st));
+    const int *d_sw = (const int *)h->d_idx, *d_tab = d_sw + nsw;
+    const unsigned char *d_ok = (const unsigned char *)(d_sw + tab_ints);
+    double *d_en = (double *)h->d_e;
+    WinHdr *d_hdr = (WinHdr *)((char *)h->d_e + sizeof(double) * (size_t)noff);
+    WinHdr *host_hdr_d = (WinHdr *)((char *)h->pin_hdr.d + 64);
+    volatile WinHdr *host_hdr = (volatile WinHdr *)((char *)h->pin_hdr.h + 64);
+    const int nslices = (nsymbols + TS_SLICE - 1) / TS_SLICE;
+    const bool exact_form = !getenv("ISEE3DSP_SEQUENTIAL") && !h->inexact_last &&
+                            grow(&h->d_part, &h->part_cap, sizeof(unsigned long long) * (size_t)nslices * (size_t)noff) == 0;
+    if (exact_form) {
+      CHK(hipMemsetAsync(h->d_flag, 0, sizeof(unsigned), h->st));
+      k_timesearch_part<<<dim3((noff + 255) / 256, nslices), 256, 0, h->st>>>(h->d_P, lo, d_sw, symbolclocks, nsymbols, noff,
+                                                                            (unsigned long long *)h->d_part, h->d_flag);
+      k_timesearch_fin<<<(noff + 255) / 256, 256, 0, h->st>>>((const unsigned long long *)h->d_part, nslices, noff, d_en, h->d_flag);
+    } else
+      k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, d_sw, symbolclocks, nsymbols, noff, d_en);
+    k_ts_argmax<<<1, 256, 0, h->st>>>(d_en, noff, d_hdr);
+    k_window_demod<<<(nsymbols + 255) / 256, 256, 0, h->st>>>(h->d_P, d_tab, nsw, first_off, spec_lo, nspec, d_ok, symbolclocks, nsymbols,
+                                                              d_hdr, exact_form ? h->d_flag : nullptr, (uint8_t *)h->pin_out.d, host_hdr_d);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(h->st));
+    const unsigned flag = exact_form ? host_hdr->inexact : 1u;
+    // the same bookkeeping as symd_timesearch: remember a window that left the exact range, look again every 32nd
+    h->inexact_last = flag ? (h->inexact_last % 32) + 1 : 0;
+    if (h->inexact_last == 32 || getenv("ISEE3DSP_RETRY_EXACT")) h->inexact_last = 0;
+    if (exact_form && flag) return 1;                               // the ordered kernel has to redo the search
+    if (host_hdr->miss || host_hdr->bi < 0) return 1;
+    const double best = host_hdr->best, me = best / nsymbols, gain = 100. / sqrt(me);
+    if (memcmp(&gain, (const void *)&host_hdr->gain, sizeof gain) != 0) return 1;   // the device rounded the gain differently: do not trust the bytes
+    *symphase = first_off + host_hdr->bi;
+    *maxenergy = me;
+    memcpy(out, h->pin_out.h, (size_t)nsymbols);
+  }
+  return 0;
+fail:
+  return -1;
+}
+
 // ===========================================================================================
 // pmdemod
 // ===========================================================================================

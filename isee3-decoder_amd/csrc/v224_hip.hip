@@ -1396,6 +1396,11 @@ static double prog_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC
 #define PROG_LOOK 24       /* ... and either decoder afterwards: feed() hands out work for some tens of ms, never the whole backlog */
 #define PROG_SLAB 8        /* chunks per call when both decoders have a backlog: their launches must interleave in the queues */
 
+// share of decoder 0's progress that decoder 1 makes while the symbols' producer still runs on the GPU ($V224HIP_PROG_GAMMA)
+static double prog_gamma(void) {
+  static const double gm = getenv("V224HIP_PROG_GAMMA") ? atof(getenv("V224HIP_PROG_GAMMA")) : 0.33;
+  return gm < -3 ? -3 : gm > 1 ? 1 : gm;
+}
 static void prog_poll(V224Prog *g, int j) {
   V224Prog::Track &t = g->tr[j];
   while (t.count > 0 && hipEventQuery(t.ev[t.head]) == hipSuccess) {
@@ -1500,9 +1505,25 @@ static int prog_advance(V224Prog *g, bool final) {
     if (final) g->can_split = false;                           // everything is known and decoder 1 never got going
     else {
       const long long a_done = g->tr[0].done;
-      long long x = (g->expected + g->warm + a_done) / 2 / q * q;
+      // Both decoders run at the same rate once all symbols are there.  While symbols still arrive, whoever produces them
+      // shares the GPU, and decoder 1 -- the second 1 024-thread workgroup on every CU -- gets less of it than decoder 0
+      // (measured in the chain, 250 kS/s and 10 MS/s: about a third of decoder 0's progress).  Balance
+      //   x - a_done - a_rate t_rem  =  expected - x + warm - gamma a_rate t_rem ,    t_rem = (expected - avail) / arrival rate,
+      // i.e. the cut moves later by (1 - gamma) a_rate t_rem / 2.  All symbols there at once: t_rem = 0, the even split.
+      long long bias = 0;
+      {
+        const double dt = prog_now() - g->t_begin;
+        if (dt > 0.05 && g->avail > 0 && g->expected > g->avail && a_done > 0) {
+          const double arrival = (double)g->avail / dt, a_rate = (double)a_done / dt;
+          const double t_rem = (double)(g->expected - g->avail) / arrival;
+          bias = (long long)((1.0 - prog_gamma()) * a_rate * t_rem / 2.0);
+        }
+      }
+      const long long x0 = (g->expected + g->warm + a_done) / 2 / q * q;          // the even split of what is left
+      long long x = ((g->expected + g->warm + a_done) / 2 + bias) / q * q;
       if (x - g->check < g->a_pos) x = (g->a_pos + g->check + q - 1) / q * q;      // (cannot happen with PROG_LOOK_PRE < warm / chunk)
-      if (x + 2 * q > g->expected) g->can_split = false;       // what would be left for decoder 1 is not worth a warm-up
+      if (x0 + 2 * q > g->expected) g->can_split = false;      // what would be left for decoder 1 is not worth a warm-up
+      else if (x + 2 * q > g->expected) { /* only the (estimated) bias says so: look again at the next feed */ }
       else if (g->avail >= x - g->warm + q && x - g->warm >= 0) {
         g->start1 = x; g->b_pos = x - g->warm; g->tr[1].done = g->b_pos;
         g->t_cut = prog_now(); g->a_done_at_cut = (double)a_done; g->avail_at_cut = (double)g->avail;
@@ -1607,7 +1628,10 @@ extern "C" int v224hip_progressive_end(void *h, uint8_t *out, long long cap, lon
     const long long a_done_end = g->tr[0].done;
     if (prog_advance(g, true) != 0) goto done;
     if (getenv("V224HIP_VERBOSE")) {
-      for (int j = 0; j < g->ndec; j++) (void)hipStreamSynchronize(g->d[j]->st);
+      double t_done[2] = {0, 0};
+      for (int j = 0; j < g->ndec; j++) { (void)hipStreamSynchronize(g->d[j]->st); t_done[j] = prog_now() - g->t_begin; }
+      fprintf(stderr, "v224hip progressive: at end() decoder 0 stood at %lld (told up to %lld), decoder 1 at %lld (told up to %lld, from %lld); decoder 0 done at %.2f ms, decoder 1 at >= %.2f ms\n",
+              a_done_end, g->a_pos, g->tr[1].done, g->b_pos, g->start1 >= 0 ? g->start1 - g->warm : -1, t_done[0], t_done[1]);
       fprintf(stderr, "v224hip progressive: %lld bits (expected %lld); cut at %lld fixed %.2f ms after begin (decoder 0 had finished %.0f, %.0f known); "
                       "end() called at %.2f ms with decoder 0 at %lld; all decoded at %.2f ms\n", g->avail, g->expected, g->start1,
               g->start1 >= 0 ? g->t_cut - g->t_begin : -1.0, g->a_done_at_cut, g->avail_at_cut, t_end - g->t_begin, a_done_end, prog_now() - g->t_begin);

@@ -61,6 +61,34 @@ def test_symdemod_host_logic_vs_reference_stdout(sym_harness, name, store):
     assert p.stdout == z[name + "/stdout"].tobytes()
 
 
+@pytest.mark.parametrize("miss", ["0", "3"], ids=["all_windows_fused", "every_third_window_stepwise"])
+@pytest.mark.parametrize("store", ["0", "1"], ids=["host_buffer", "engine_store"])
+@pytest.mark.parametrize("name", [str(n) for n in np.load(SG)["names"]])
+def test_symdemod_fused_window_path_vs_reference_stdout(sym_harness, name, store, miss):
+    """the window loop through the engine's fused `window` call (search, first maximum and final demodulation behind one
+    synchronisation; the final demodulation's boundary tables speculated for timing adjustments -2 .. +2) gives the
+    reference's stdout -- also when the engine sends every third window back to the step-by-step calls, and (clock
+    tracking, `-t`) when the core must not use it at all"""
+    z = np.load(SG)
+    bb = sym_input(z, name)
+    args = [str(a) for a in z[name + "/args"]]
+    p = subprocess.run([sym_harness] + args, input=bb.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True,
+                       timeout=600, env=dict(os.environ, SYMD_STORE=store, SYMD_WINDOW="1", SYMD_WINDOW_MISS=miss))
+    assert p.stdout == z[name + "/stdout"].tobytes()
+    if "-t" in args:
+        assert b"WINDOW calls=" not in p.stderr           # clock tracking: the step-by-step path only
+    else:
+        import re
+        m = re.search(rb"WINDOW calls=(\d+) done=(\d+)", p.stderr)
+        assert m and int(m.group(1)) > 0
+        calls, done = int(m.group(1)), int(m.group(2))
+        assert done <= calls and (miss == "0" or done <= calls - calls // 3)
+        if miss == "0" and "64bps" not in name:
+            # the first window aligns by up to half a symbol (outside the speculated +-2 samples: step-by-step), the later
+            # ones track within a sample; the 64 bit/s fixture drifts by more than two samples per 2 s window: never fused
+            assert done >= calls - 1
+
+
 def _pm_args(cfg):
     a = ["-q", "-r", repr(float(cfg[0])), "-b", repr(float(cfg[1]))]
     if cfg[2]: a += ["-S", repr(float(cfg[2]))]
