@@ -1,8 +1,9 @@
 #!/bin/bash
+# (R03TAG=r03u bash scratch/r03h.sh writes to gpurun_out/r03u: the same call on a later build)
 # round 3: whole GPU suite, default bench line, kernel traces (lone-decoder run and default run), PMC of k_acs_lds15
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-OUT=gpurun_out/r03h; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/${R03TAG:-r03h}; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; rc=$?; tail -4 $OUT/pytest.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 500 python3 bench.py --steps 2 --warmup 1 > $OUT/bench_default.json 2> $OUT/bench_default.err || { tail -5 $OUT/bench_default.err; exit 1; }
