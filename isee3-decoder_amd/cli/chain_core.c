@@ -400,7 +400,7 @@ static int iq_next(void *p, int N, const int16_t **blk, int *is_dev) {
 }
 
 typedef struct { pmdemod_opts o; iq_src src; blkchan *out; int rc; double ms; } pm_arg;
-typedef struct { symdemod_opts o; blkchan *in; FILE *out; int rc; double ms; volatile int *done; } sy_arg;
+typedef struct { symdemod_opts o; blkchan *in; FILE *out; int rc; double ms; volatile int *done; double t0, t_done; } sy_arg;
 typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; volatile int *front_done; long long expected_bits; int progressive; } vd_arg;
 
 static void *pm_thread(void *p) {
@@ -426,6 +426,7 @@ static void *sy_thread(void *p) {
   t_stage_ms = 0;
   a->rc = symdemod_run_blk(&a->o, &e, blk_next, a->in, a->out, stderr);
   a->ms = t_stage_ms;
+  a->t_done = now_ms() - a->t0;
   __atomic_store_n(a->done, 1, __ATOMIC_RELEASE);    /* before the pipe closes: what vdecode reads from now on is all there is */
   fclose(a->out);
   blk_reader_gone(a->in);
@@ -498,6 +499,7 @@ static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   sa.in = &c1; sa.out = fdopen(p2[1], "w"); sa.done = &front_done;
   va.fd_in = p2[0]; va.out = out; va.front_done = &front_done;
   pthread_t t1, t2, t3;
+  sa.t0 = now_ms(); sa.t_done = 0;
   pthread_create(&t1, NULL, pm_thread, &pa);
   pthread_create(&t2, NULL, sy_thread, &sa);
   pthread_create(&t3, NULL, vd_thread, &va);
@@ -505,6 +507,8 @@ static int chain_run(const isee3_chain_opts *co, const iq_src *src, FILE *out) {
   blk_free(&c1);
   free(pa.src.buf);
   g_stage_ms[0] = pa.ms; g_stage_ms[1] = sa.ms; g_stage_ms[2] = va.ms;
+  if (getenv("V224HIP_VERBOSE"))
+    fprintf(stderr, "isee3chain: last symbol out of symdemod %.2f ms after the start, all stages done after %.2f ms\n", sa.t_done, now_ms() - sa.t0);
   if (!pa.rc && !sa.rc && va.rc == -2) {
     snprintf(g_chain_err, sizeof g_chain_err, "vdecode: the decoded bits could not be written (output buffer too small, or the output was closed)");
     return 2;
