@@ -414,16 +414,24 @@ def segmented_record(a, ctx, iq, sent, fs, binsize, nseg, warm_blocks, steps, wa
             "check": {"decoded_run_found_in_sent_stream": ok, "all_seams_verified": bool(seams and seams["matched"] == seams["total"])}}
 
 
-def stress_record(a, ctx):
-    """BASELINE configs[4] in the default line: 10 MS/s, 1 Hz bins (N = 2^23), 64 overlapped segments of one block each
-    (+ 7 warm-up blocks), full-band search.  The 64-block capture (2.1 GB) is generated once, in parallel."""
-    synth = ctx["synth"]
-    fs, N = 1.0e7, 1 << 23
-    workers = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, ctx["world"])))
+def stress_capture(a, world):
+    """The 64-block 10 MS/s capture of the stress record (2.1 GB), generated once per run by forked worker processes.
+    Called BEFORE this process imports torch.cuda or loads a HIP library: the workers must not inherit an initialised GPU
+    runtime (no fork of a process that holds the device)."""
+    from importlib import import_module
+    load_pkg()
+    synth = import_module("isee3_decoder_amd.synth")
+    workers = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world)))
     t0 = time.perf_counter()
-    iq, sent = synth.iq_capture_parallel(3, fs, a.stress_blocks * N, workers=workers)
-    gen_s = time.perf_counter() - t0
-    rec = segmented_record(a, ctx, iq, sent, fs, 1.0, a.stress_segments, 7, max(1, min(a.steps, 2)), 1)
+    iq, sent = synth.iq_capture_parallel(3, 1.0e7, a.stress_blocks * (1 << 23), workers=workers)
+    return iq, sent, time.perf_counter() - t0
+
+
+def stress_record(a, ctx, capture):
+    """BASELINE configs[4] in the default line: 10 MS/s, 1 Hz bins (N = 2^23), 64 overlapped segments of one block each
+    (+ 7 warm-up blocks), full-band search, on the capture stress_capture() made at the start of the run."""
+    iq, sent, gen_s = capture
+    rec = segmented_record(a, ctx, iq, sent, 1.0e7, 1.0, a.stress_segments, 7, max(1, min(a.steps, 2)), 1)
     if rec is not None:
         rec["capture_generated_in_s"] = round(gen_s, 1)
     return rec
@@ -531,6 +539,8 @@ def main():
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (a.gpus, world))
     if a.dry_ranks:
         return dry_ranks(a, rank, world)
+    # the stress record's capture: made now, by forked workers, while this process has not touched a device yet
+    capture = stress_capture(a, world) if a.workload == "viterbi" and not a.no_chain and not a.no_stress else None
 
     import torch
     import torch.distributed as dist
@@ -674,8 +684,9 @@ def main():
                              world == 1 and not a.no_cpu)
         pkg.release_chain_objects()
     stress = None
-    if not a.no_chain and not a.no_stress:
-        stress = stress_record(a, ctx)
+    if capture is not None:
+        stress = stress_record(a, ctx, capture)
+        capture = None
         pkg.release_chain_objects()
 
     if rank == 0:
