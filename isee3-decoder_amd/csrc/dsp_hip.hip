@@ -278,6 +278,52 @@ __global__ __launch_bounds__(64) void k_timesearch(const long long *__restrict__
   energies[t] = energy;
 }
 
+// The same ordered sum with four waves per 64 offsets: the kernel above is pure load latency -- it reads the window's WHOLE
+// prefix array (9 761 offsets x 2 049 boundaries x 8 B = 160 MB at 10 MS/s) with 153 waves and at most 63 loads each in
+// flight.  Here wave w of a workgroup forms the terms (double)(sym * sym) of symbols [128 r + 32 w, + 32) for the
+// workgroup's 64 offsets -- the same integer products, the same conversions -- and parks them in LDS; wave 0 then adds
+// the round's 128 terms IN ORDER (the reference's order of additions, bit for bit) while nothing else changes.  Four times
+// the loads in flight.  symbolclocks == 1 only.
+#define TS4_SYMS 32                      /* symbols per wave and round (2 x 32 + 1 loads) */
+__global__ __launch_bounds__(256) void k_timesearch4(const long long *__restrict__ P, int lo, const int *__restrict__ sw,
+                                                     int nsymbols, int noff, double *__restrict__ energies) {
+  extern __shared__ double ts4_terms[];                    // [4 * TS4_SYMS][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const long long *Pb = P + lo + (t < noff ? t : noff - 1);       // lanes beyond the last offset repeat it (their result is dropped)
+  double energy = 0;
+  for (int r0 = 0; r0 < nsymbols; r0 += 4 * TS4_SYMS) {
+    const int i0 = r0 + w * TS4_SYMS;
+    if (i0 + TS4_SYMS <= nsymbols) {
+      long long pv[2 * TS4_SYMS + 1];
+#pragma unroll
+      for (int u = 0; u <= 2 * TS4_SYMS; u++) pv[u] = Pb[sw[2 * i0 + u]];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u <= 2 * TS4_SYMS; u++) asm volatile("" : "+v"(pv[u]));
+#pragma unroll
+      for (int u = 0; u < TS4_SYMS; u++) {
+        const long long a = pv[2 * u], b = pv[2 * u + 1], c = pv[2 * u + 2];
+        const long long sym = -(b - a) + (c - b);
+        ts4_terms[(w * TS4_SYMS + u) * 64 + lane] = (double)(sym * sym);
+      }
+    } else {
+      for (int u = 0; u < TS4_SYMS && i0 + u < nsymbols; u++) {
+        const long long a = Pb[sw[2 * (i0 + u)]], b = Pb[sw[2 * (i0 + u) + 1]], c = Pb[sw[2 * (i0 + u) + 2]];
+        const long long sym = -(b - a) + (c - b);
+        ts4_terms[(w * TS4_SYMS + u) * 64 + lane] = (double)(sym * sym);
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+      const int n = nsymbols - r0 < 4 * TS4_SYMS ? nsymbols - r0 : 4 * TS4_SYMS;
+      for (int u = 0; u < n; u++) energy += ts4_terms[u * 64 + lane];
+    }
+    __syncthreads();                                       // the terms have been consumed: the next round may overwrite them
+  }
+  if (w == 0 && t < noff) energies[t] = energy;
+}
+
 // Parallel form of the same sum.  The reference adds (double)(sym*sym) symbol by symbol; as long as
 // every term and the running total stay below 2^53 each partial sum is an exactly representable integer
 // and the order of addition cannot matter, so the sum may be formed in u64 by many threads.  Thread =
@@ -496,6 +542,22 @@ extern "C" int symd_load(void *p, const int16_t *samples, int n, int is_dev) {
   if (symd_store_put(p, 0, samples, n, is_dev) != 0) return -1;
   return symd_store_scan(p, n);
 }
+// the ordered timing search: four waves per 64 offsets where it applies (ISEE3DSP_TS1=1: the one-wave kernel)
+static int launch_ordered_search(Symd *h, int lo, const int *d_sw, int symbolclocks, int nsymbols, int noff, double *d_en) {
+  static const bool one_wave = getenv("ISEE3DSP_TS1") && atoi(getenv("ISEE3DSP_TS1")) != 0;
+  if (symbolclocks == 1 && !one_wave) {
+    const size_t lds = sizeof(double) * 4 * TS4_SYMS * 64;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << (h->dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+      if (hipFuncSetAttribute((const void *)k_timesearch4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      attr_set.fetch_or(bit, std::memory_order_release);
+    }
+    k_timesearch4<<<(noff + 63) / 64, 256, lds, h->st>>>(h->d_P, lo, d_sw, nsymbols, noff, d_en);
+  } else
+    k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, d_sw, symbolclocks, nsymbols, noff, d_en);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks, int nsymbols, int noff,
                                double *energies) {
   Symd *h = (Symd *)p;
@@ -534,8 +596,7 @@ extern "C" int symd_timesearch(void *p, int lo, const int *sw, int symbolclocks,
     h->inexact_last = flag ? (h->inexact_last % 32) + 1 : 0;
     if (h->inexact_last == 32 || getenv("ISEE3DSP_RETRY_EXACT")) h->inexact_last = 0;
     if (flag) {     // some sum left the exactly-representable range: the reference's own order of additions
-      k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, (const int *)h->d_idx, symbolclocks, nsymbols,
-                                                       noff, (double *)h->pin_e.d);
+      if (launch_ordered_search(h, lo, (const int *)h->d_idx, symbolclocks, nsymbols, noff, (double *)h->pin_e.d) != 0) goto fail;
       CHK(hipGetLastError());
       CHK(hipStreamSynchronize(h->st));
     }
@@ -681,8 +742,7 @@ extern "C" int symd_window(void *p, int firstsample, const int *sw, int symbolcl
       k_timesearch_part<<<dim3((noff + 255) / 256, nslices), 256, 0, h->st>>>(h->d_P, lo, d_sw, symbolclocks, nsymbols, noff,
                                                                             (unsigned long long *)h->d_part, h->d_flag);
       k_timesearch_fin<<<(noff + 255) / 256, 256, 0, h->st>>>((const unsigned long long *)h->d_part, nslices, noff, d_en, h->d_flag);
-    } else
-      k_timesearch<<<(noff + 63) / 64, 64, 0, h->st>>>(h->d_P, lo, d_sw, symbolclocks, nsymbols, noff, d_en);
+    } else if (launch_ordered_search(h, lo, d_sw, symbolclocks, nsymbols, noff, d_en) != 0) goto fail;
     k_ts_argmax<<<1, 256, 0, h->st>>>(d_en, noff, d_hdr);
     k_window_demod<<<(nsymbols + 255) / 256, 256, 0, h->st>>>(h->d_P, d_tab, nsw, first_off, spec_lo, nspec, d_ok, symbolclocks, nsymbols,
                                                               d_hdr, exact_form ? h->d_flag : nullptr, (uint8_t *)h->pin_out.d, host_hdr_d);
@@ -984,19 +1044,32 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
         u_first[k2] = val;                                  // parked: leaves through the LDS transpose below
       }
     } else {
-      // later stages: ONE ps per tile, so a lookup is a broadcast that hits the L1 / L2; looked up value by value.  (Issuing
-      // all 2 R2 table loads first was measured too: 150 -> 217 VGPRs at R = 256 and the passes got SLOWER beside a running
-      // decoder, 72 -> 78 and 60 -> 78 us at N = 2^23.)
+      // later stages: ONE ps per tile.  W^(ps k), k = k1 + R1 k2, is walked like the first stage's: two table lookups
+      // (W^(ps k1), W^(ps R1)) and R2 products instead of 2 R2 dependent lookups (the compiler waited for each one: up to
+      // 32 L2 round trips per thread); <= 15 products deep, ~1e-15 relative.  FFT_LOOKUP_ALL=1 (bench builds) keeps the
+      // value-by-value lookups.
+#ifndef FFT_LOOKUP_ALL
+#define FFT_LOOKUP_ALL 0
+#endif
+      double2 wk = make_double2(1.0, 0.0), wstep = wk;
+      if (!FFT_LOOKUP_ALL) {
+        const unsigned i1 = (unsigned)ps * (unsigned)r, i2 = (unsigned)ps * (unsigned)R1;
+        const double2 b1 = twB[i1 & 4095u], a1 = twA[i1 >> 12], b2 = twB[i2 & 4095u], a2 = twA[i2 >> 12];
+        if (ps != 0) { wk = tw2_sel(i1, b1, a1); wstep = tw2_sel(i2, b2, a2); }
+      }
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++) {
         const int k = r + R1 * k2;
         double2 val = u[brev(k2, lg2c(R2))];
         if (ps != 0 && k != 0) {
-          const unsigned idx = (unsigned)ps * (unsigned)k;
-          double2 w = twB[idx & 4095u];
-          if (idx >> 12) w = cmul(twA[idx >> 12], w);
-          val = cmul(val, w);
+          if (FFT_LOOKUP_ALL) {
+            const unsigned idx = (unsigned)ps * (unsigned)k;
+            double2 w = twB[idx & 4095u];
+            if (idx >> 12) w = cmul(twA[idx >> 12], w);
+            val = cmul(val, w);
+          } else val = cmul(val, wk);
         }
+        if (!FFT_LOOKUP_ALL) wk = cmul(wk, wstep);
         out[(size_t)k * s] = val;
         if constexpr (PEAK) {
           const int i = q + R * ps + k * s;                 // the bin this value is (the last pass: N fits an int)
