@@ -113,6 +113,16 @@ int pmd_fft_peak(void *h, int firstbin, int lastbin, pmd_peak *out);
  * rotate carrier onto the real axis, noise variance, quantise Im * sqrt(1/2) to int16.
  * out16 / pre (optional pre-quantisation doubles) are host pointers, or device if out_is_dev. */
 int pmd_mix_quantise(void *h, double cstep_rad, pmd_mix *res, int16_t *out16, double *pre, int out_is_dev);
+/* The same two calls in an asynchronous form: *_begin enqueues the work on the handle's stream and records an event,
+ * *_end waits for that event alone and reads the results (pmd_fft_peak == begin + end; pmd_mix_quantise likewise).  Two
+ * handles on one stream can thus overlap one block's transform with the host's work on the previous block -- and with its
+ * spin-down passes, which read only the int16 block, never the spectrum.  pmd_mix_begin returns 1 (nothing enqueued) for
+ * a block the stepped-carrier kernels do not take (under 1 024 samples, unaligned buffers): use pmd_mix_quantise then.
+ * The int16 block announced by pmd_load must stay valid until pmd_mix_end has returned. */
+int pmd_fft_peak_begin(void *h, int firstbin, int lastbin);
+int pmd_fft_peak_end(void *h, pmd_peak *out);
+int pmd_mix_begin(void *h, double cstep_rad, int16_t *out16, double *pre, int out_is_dev);
+int pmd_mix_end(void *h, pmd_mix *res);
 /* test hook: copy the spectrum (fftsize complex doubles) to host */
 int pmd_get_spectrum(void *h, double *out_ri);
 

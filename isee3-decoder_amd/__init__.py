@@ -267,6 +267,7 @@ DSP_SYMBOLS = [
     "symd_create", "symd_destroy", "symd_load", "symd_timesearch", "symd_demod",
     "symd_store_reset", "symd_store_slide", "symd_store_put", "symd_store_scan", "symd_window",
     "pmd_create", "pmd_destroy", "pmd_set_dechirp", "pmd_load", "pmd_fft_peak", "pmd_mix_quantise",
+    "pmd_fft_peak_begin", "pmd_fft_peak_end", "pmd_mix_begin", "pmd_mix_end",
     "pmd_get_spectrum",
     "isync_create", "isync_destroy", "isync_set_vector", "isync_search",
 ]

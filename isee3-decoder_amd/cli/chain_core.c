@@ -88,6 +88,28 @@ static int pm_mix_any(void *h, double cstep, pmdemod_mix *r, int16_t *out16, int
 }
 static int pm_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) { return pm_mix_any(h, cstep, r, out16, 0); }
 static int pm_mix_dev(void *h, double cstep, pmdemod_mix *r, int16_t *d_out16) { return pm_mix_any(h, cstep, r, d_out16, 1); }
+/* the asynchronous halves (pmdemod_core.h): block k+1's transform is in the front-end stream before block k's peak is awaited */
+static int pm_peak_begin(void *h, int a, int b) { TIMED(pmd_fft_peak_begin(PMH(h), a, b)); }
+static int pm_peak_end(void *h, pmdemod_peak *o) {
+  pmd_peak p;
+  double t0 = now_ms();
+  int rc = pmd_fft_peak_end(PMH(h), &p);
+  t_stage_ms += now_ms() - t0;
+  if (rc != 0) return -1;
+  o->peak = p.peak; o->maxenergy = p.maxenergy; o->peak_re = p.peak_re; o->peak_im = p.peak_im;
+  o->next_re = p.next_re; o->next_im = p.next_im; o->prev_re = p.prev_re; o->prev_im = p.prev_im;
+  return 0;
+}
+static int pm_mix_begin(void *h, double cstep, int16_t *out16, int out_is_dev) { TIMED(pmd_mix_begin(PMH(h), cstep, out16, NULL, out_is_dev)); }
+static int pm_mix_end(void *h, pmdemod_mix *r) {
+  pmd_mix m;
+  double t0 = now_ms();
+  int rc = pmd_mix_end(PMH(h), &m);
+  t_stage_ms += now_ms() - t0;
+  if (rc != 0) return -1;
+  r->dc_re = m.dc_re; r->dc_im = m.dc_im; r->amplitude = m.amplitude; r->diffsumsq = m.diffsumsq;
+  return 0;
+}
 static void pm_destroy(void *p) {
   dsp_ctx *c = p;
   if (!c) return;
@@ -276,7 +298,7 @@ static int vd_prog_end(void *h, long long n, int d, unsigned char *o) { TIMED(vd
 /* ---- block channel pmdemod -> symdemod: a ring of device slots, each one baseband block (N int16).  pmdemod acquires
  * a free slot, lets the engine write the block into it, commits it; symdemod takes views of committed slots in order
  * and copies them device-to-device into its window buffer.  No sample passes through host memory. ---- */
-#define NSLOT 3
+#define NSLOT 4
 typedef struct {
   pthread_mutex_t mu; pthread_cond_t cv;
   int16_t *slot[NSLOT]; int N;
@@ -405,7 +427,14 @@ typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; volati
 
 static void *pm_thread(void *p) {
   pm_arg *a = p;
-  pmdemod_engine e = { pm_create, pm_dechirp, pm_load, pm_peak, pm_mix, pm_destroy, pm_load_dev, pm_mix_dev };
+  pmdemod_engine e = { pm_create, pm_dechirp, pm_load, pm_peak, pm_mix, pm_destroy, pm_load_dev, pm_mix_dev, NULL, NULL, NULL, NULL };
+  /* ISEE3_CHAIN_PM_PIPELINE=1: two pmdemod handles in turn, block k+1's transform enqueued before block k's peak is awaited
+   * (pmdemod_core.h).  Measured: pmdemod's engine time 6.0 -> 2.9 ms at 250 kS/s -- and the chain not a bit faster at either
+   * rate (its front end is paced by symdemod's windows and by the decoders on the same CUs), 7 % slower from a capture in
+   * pageable host memory (the next block's staged H2D copy queues in front of this block's spin-down).  Off by default. */
+  if (getenv("ISEE3_CHAIN_PM_PIPELINE") && atoi(getenv("ISEE3_CHAIN_PM_PIPELINE"))) {
+    e.fft_peak_begin = pm_peak_begin; e.fft_peak_end = pm_peak_end; e.mix_begin = pm_mix_begin; e.mix_end = pm_mix_end;
+  }
   pmdemod_source src = { iq_next, &a->src };
   pmdemod_sink dst = { blk_acquire, blk_commit, a->out };
   t_stage_ms = 0;

@@ -137,6 +137,78 @@ int pmdemod_run_io(const pmdemod_opts *o, const pmdemod_engine *e, const pmdemod
     }
   }
 
+  if (Search_width == 0 && e->fft_peak_begin && e->fft_peak_end && e->mix_begin && e->mix_end &&
+      !(getenv("PMDEMOD_SERIAL") && atoi(getenv("PMDEMOD_SERIAL")))) {
+    /* Independent blocks (full-band search, pmdemod.c:273-276: nothing of a block's result enters the next one's search),
+       two handles A / B used in turn.  Engine queue: FFT(0) FFT(1) mix(0) FFT(2) mix(1) ... -- block k+1's transform is
+       enqueued before block k's peak is waited for, so the engine works while the host forms Quinn's estimate and the
+       carrier parameters; block k-1 (sums, status line, commit) is finished in iteration k.  Same calls, same values,
+       same order of output as the loop below. */
+    void *hh[2] = { h, e->create(N) };
+    struct { int active, async_mix, peak; double carrier_freq; int16_t *out16; pmdemod_mix mx; } b[2];
+    memset(b, 0, sizeof b);
+    int k = 0, more = 1, bad = hh[1] == NULL || (lo && e->set_dechirp(hh[1], lo) != 0);
+    const int16_t *iq = NULL; int in_dev = 0;
+    if (!bad) {
+      int got = src->next(src->ctx, N, &iq, &in_dev);
+      if (got == 0) more = 0;
+      else if (got < 0 || (in_dev && !e->load_dev) || (in_dev ? e->load_dev(hh[0], iq, o->flip ? 1 : 0) : e->load(hh[0], iq, o->flip ? 1 : 0)) != 0 ||
+               e->fft_peak_begin(hh[0], 0, N) != 0) bad = 1;
+    }
+    while (!bad && more) {
+      const int cur = k & 1, nxt = cur ^ 1;
+      int have_next = 0;
+      {                                               /* (1) the next block's transform goes into the queue */
+        int got = src->next(src->ctx, N, &iq, &in_dev);
+        if (got < 0 || (got > 0 && in_dev && !e->load_dev)) { bad = 1; break; }
+        if (got > 0) {
+          if ((in_dev ? e->load_dev(hh[nxt], iq, o->flip ? 1 : 0) : e->load(hh[nxt], iq, o->flip ? 1 : 0)) != 0 ||
+              e->fft_peak_begin(hh[nxt], 0, N) != 0) { bad = 1; break; }
+          have_next = 1;
+        }
+      }
+      pmdemod_peak pk;                                /* (2) this block's peak, Quinn's estimate (pmdemod.c:299-318) */
+      if (e->fft_peak_end(hh[cur], &pk) != 0 || pk.peak < 0) { bad = 1; break; }
+      double ap = (pk.next_re * pk.peak_re + pk.next_im * pk.peak_im) / pk.maxenergy;
+      double dp = -ap / (1 - ap);
+      double am = (pk.prev_re * pk.peak_re + pk.prev_im * pk.peak_im) / pk.maxenergy;
+      double dm = am / (1 - am);
+      double d = (dp + dm) / 2 + tau(dp * dp) - tau(dm * dm);
+      double carrier_freq = Binsize * (pk.peak + d);
+      if (carrier_freq > Samprate / 2) carrier_freq -= Samprate;
+      double cstep = 2 * M_PI * carrier_freq / Samprate;
+      for (int pass = 0; pass < 2 && !bad; pass++) {  /* (3) the previous block leaves, (4) this block's spin-down is enqueued; at the end: (3) for this block too */
+        const int j = pass == 0 ? nxt : cur;
+        if (pass == 1) {
+          int out_dev = 0;
+          int16_t *out16 = dst->acquire(dst->ctx, N, &out_dev);
+          if (!out16 || (out_dev && !e->mix_dev)) { bad = 1; break; }
+          int r = e->mix_begin(hh[cur], cstep, out16, out_dev);
+          if (r < 0 || (r == 1 && (out_dev ? e->mix_dev(hh[cur], cstep, &b[cur].mx, out16) : e->mix(hh[cur], cstep, &b[cur].mx, out16)) != 0)) { bad = 1; break; }
+          b[cur].active = 1; b[cur].async_mix = r == 0; b[cur].peak = pk.peak; b[cur].carrier_freq = carrier_freq; b[cur].out16 = out16;
+          if (have_next) break;                       /* it is finished in the next iteration */
+        }
+        if (!b[j].active) continue;
+        if (b[j].async_mix && e->mix_end(hh[j], &b[j].mx) != 0) { bad = 1; break; }
+        cn0 = 10 * log10(Samprate * b[j].mx.amplitude * b[j].mx.amplitude / (2 * b[j].mx.diffsumsq));
+        if (!o->quiet)
+          fprintf(err, "%s: sample %'lld (%'.3lf sec, %s); carrier %'.1lf Hz; C/No = %'.2lf dB%s\n", o->argv0,
+                  total_samples, total_samples / Samprate, isee3_format_hms(total_samples / Samprate), b[j].carrier_freq,
+                  cn0, cn0 >= o->cn0_threshold ? " locked" : "");
+        if (report && nb < report_cap) { report[nb].peak = b[j].peak; report[nb].carrier_freq = b[j].carrier_freq; report[nb].cn0 = cn0; }
+        nb++;
+        if (dst->commit(dst->ctx, b[j].out16, N) != 0) { bad = 1; break; }
+        total_samples += N;
+        b[j].active = 0;
+      }
+      more = have_next;
+      k++;
+    }
+    if (bad) exitcode = 2;
+    if (hh[1]) e->destroy(hh[1]);
+    goto done;
+  }
+
   for (;;) {
     /* a whole block or nothing: the remainder of the input is dropped (pmdemod.c:206-216) */
     const int16_t *iq = NULL; int in_dev = 0;

@@ -35,6 +35,14 @@ typedef struct {
      that are already, or shall stay, in device memory */
   int   (*load_dev)(void *h, const int16_t *d_iq, int flip);
   int   (*mix_dev)(void *h, double cstep, pmdemod_mix *res, int16_t *d_out16);
+  /* optional (all four or none): fft_peak and mix split into enqueue / collect (include/isee3_dsp_hip.h: pmd_*_begin / _end).
+     With them -- and blocks that do not depend on each other (-W 0) -- pmdemod_run_io alternates TWO handles so that block
+     k+1's transform is in the engine's queue before block k's peak is waited for, and a block is handed on one iteration
+     later.  mix_begin: 0 enqueued, 1 this block takes mix() / mix_dev(), < 0 error. */
+  int   (*fft_peak_begin)(void *h, int firstbin, int lastbin);
+  int   (*fft_peak_end)(void *h, pmdemod_peak *out);
+  int   (*mix_begin)(void *h, double cstep, int16_t *out16, int out_is_dev);
+  int   (*mix_end)(void *h, pmdemod_mix *res);
 } pmdemod_engine;
 
 /* where blocks come from / go to when they are not a FILE: views, so a capture in memory (host or device) is read in

@@ -787,6 +787,7 @@ struct Pmd {
   const int16_t *cur_iq; int cur_flip;   // the block pmd_load announced (device memory): read by the FFT's first pass,
                                          // by the spin-down sum and by the output kernel -- no double-precision copy of it exists
   void *d_red; size_t red_cap;           // reduction scratch
+  hipEvent_t ev_peak, ev_mix;            // behind the transform + peak kernels / behind the two spin-down passes (the *_begin / *_end calls)
   void *d_peakpart; size_t peakpart_cap; // one peak record per workgroup of the last FFT pass
   int16_t *d_out16; double *d_pre;
   int have_lo;
@@ -1449,6 +1450,8 @@ extern "C" void *pmd_create(int fftsize) {
   h->red_cap = sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak) + sizeof(PeakRec) * RED_BLOCKS;
   CHK(hipMalloc(&h->d_red, h->red_cap));
   if (pin_grow(&h->pin_hdr, 256) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: pinned mailbox"); goto fail; }
+  CHK(hipEventCreateWithFlags(&h->ev_peak, hipEventDisableTiming));
+  CHK(hipEventCreateWithFlags(&h->ev_mix, hipEventDisableTiming));
   if (lg >= 12 && !getenv("ISEE3DSP_FFT_REGISTER_RADIX")) {
     FftCtx c;
     if (fft_tables(&c, fftsize, &h->twA, &h->twB, &h->twR, h->st) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: twiddle tables"); goto fail; }
@@ -1473,6 +1476,8 @@ extern "C" void pmd_destroy(void *p) {
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
   (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red); (void)hipFree(h->d_peakpart);
   pin_free(&h->pin_hdr);
+  if (h->ev_peak) (void)hipEventDestroy(h->ev_peak);
+  if (h->ev_mix) (void)hipEventDestroy(h->ev_mix);
   free(h);
 }
 // de-chirp LO table (N complex doubles = the lophase sequence of pmdemod.c:237-243, computed by the
@@ -1509,7 +1514,25 @@ extern "C" int pmd_load(void *p, const int16_t *iq, int is_dev, int flip) {
 fail:
   return -1;
 }
+// The two engine calls of a block in an asynchronous form: *_begin enqueues and records an event, *_end waits for exactly
+// that event and reads the results out of the pinned mailbox.  A caller that alternates two handles on one stream can then
+// have block k+1's transform in the stream before it waits for block k's (cli/pmdemod_core.c), instead of leaving the GPU
+// idle while the host forms Quinn's estimate and the quad-precision carrier parameters.
+extern "C" int pmd_fft_peak_end(void *p, pmd_peak *out) {
+  Pmd *h = (Pmd *)p;
+  if (!h || !out) return -1;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipEventSynchronize(h->ev_peak));
+  memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
+  return 0;
+fail:
+  return -1;
+}
 extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
+  if (pmd_fft_peak_begin(p, firstbin, lastbin) != 0) return -1;
+  return pmd_fft_peak_end(p, out);
+}
+extern "C" int pmd_fft_peak_begin(void *p, int firstbin, int lastbin) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;
   if (firstbin < 0 || lastbin > h->N || firstbin > lastbin) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: bad bin range"); return -1; }
@@ -1554,8 +1577,54 @@ extern "C" int pmd_fft_peak(void *p, int firstbin, int lastbin, pmd_peak *out) {
     else k_peak_partial<<<nb, 256, 0, h->st>>>(h->spec, firstbin, lastbin, part);
     k_peak_final<<<1, 256, 0, h->st>>>(part, nb, h->spec, h->N, (pmd_peak *)h->pin_hdr.d);      // straight into mapped host memory
     CHK(hipGetLastError());
-    CHK(hipStreamSynchronize(h->st));
-    memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
+    CHK(hipEventRecord(h->ev_peak, h->st));
+  }
+  return 0;
+fail:
+  return -1;
+}
+// 0 enqueued (pmd_mix_end collects); 1 this block takes the synchronous call (small or unaligned, ISEE3DSP_CARRIER_CLOSED=1)
+extern "C" int pmd_mix_begin(void *p, double cstep, int16_t *out16, double *pre, int out_is_dev) {
+  Pmd *h = (Pmd *)p;
+  if (!h) return -1;
+  if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_mix_quantise: no block loaded"); return -1; }
+  CHK(hipSetDevice(h->dev));
+  {
+    double2 *part = (double2 *)h->d_red, *tot = part + RED_BLOCKS;
+    const short2 *iq = (const short2 *)h->cur_iq;
+    const double2 *lo = h->have_lo ? h->lo : nullptr;
+    int16_t *o16v = (out16 && out_is_dev) ? out16 : h->d_out16;
+    double *oprev = pre ? (out_is_dev ? pre : h->d_pre) : nullptr;
+    static const bool closed_form = getenv("ISEE3DSP_CARRIER_CLOSED") && atoi(getenv("ISEE3DSP_CARRIER_CLOSED")) != 0;
+    if (closed_form || h->N < 1024 || ((uintptr_t)iq & 15u) != 0 || ((uintptr_t)o16v & 7u) != 0 || ((uintptr_t)oprev & 15u) != 0) return 1;
+    uint64_t u_hi, u_lo; double logrho;
+    pmd_carrier_params(cstep, &u_hi, &u_lo, &logrho);
+    // stepped carrier, four samples per thread and step, both passes and their sums without a host round trip in between
+    int nb4 = (h->N / 4 + 255) / 256; if (nb4 > RED_BLOCKS) nb4 = RED_BLOCKS;
+    double2 *cs = tot + 8;
+    k_carrier_steps<<<1, 64, 0, h->st>>>(u_hi, u_lo, logrho, 4ull * (unsigned long long)nb4 * 256ull, cs);
+    k_mix4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, part);
+    k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 128), tot);
+    k_rotate4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, tot, o16v, oprev, part);
+    k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 144));
+    CHK(hipGetLastError());
+    if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
+    if (pre && !out_is_dev) CHK(hipMemcpyAsync(pre, h->d_pre, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
+    CHK(hipEventRecord(h->ev_mix, h->st));
+  }
+  return 0;
+fail:
+  return -1;
+}
+extern "C" int pmd_mix_end(void *p, pmd_mix *res) {
+  Pmd *h = (Pmd *)p;
+  if (!h || !res) return -1;
+  CHK(hipSetDevice(h->dev));
+  CHK(hipEventSynchronize(h->ev_mix));
+  {
+    const volatile double *m = (const volatile double *)((char *)h->pin_hdr.h + 128);
+    const double dcr = m[0] / h->N, dci = m[1] / h->N;
+    res->dc_re = dcr; res->dc_im = dci; res->amplitude = hypot(dcr, dci); res->diffsumsq = m[2] / h->N;
   }
   return 0;
 fail:
@@ -1564,36 +1633,19 @@ fail:
 extern "C" int pmd_mix_quantise(void *p, double cstep, pmd_mix *res, int16_t *out16, double *pre, int out_is_dev) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;
-  if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_mix_quantise: no block loaded"); return -1; }
+  {
+    const int b = pmd_mix_begin(p, cstep, out16, pre, out_is_dev);
+    if (b < 0) return -1;
+    if (b == 0) return pmd_mix_end(p, res);
+  }
   CHK(hipSetDevice(h->dev));
   {
     uint64_t u_hi, u_lo; double logrho;
     pmd_carrier_params(cstep, &u_hi, &u_lo, &logrho);
-    double2 *part = (double2 *)h->d_red, *tot = part + RED_BLOCKS;
+    double2 *part = (double2 *)h->d_red;
     const short2 *iq = (const short2 *)h->cur_iq;
     const double2 *lo = h->have_lo ? h->lo : nullptr;
     int nb = (h->N + 255) / 256; if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-    int16_t *o16v = (out16 && out_is_dev) ? out16 : h->d_out16;
-    double *oprev = pre ? (out_is_dev ? pre : h->d_pre) : nullptr;
-    static const bool closed_form = getenv("ISEE3DSP_CARRIER_CLOSED") && atoi(getenv("ISEE3DSP_CARRIER_CLOSED")) != 0;
-    if (!closed_form && h->N >= 1024 && ((uintptr_t)iq & 15u) == 0 && ((uintptr_t)o16v & 7u) == 0 && ((uintptr_t)oprev & 15u) == 0) {
-      // stepped carrier, four samples per thread and step, both passes and their sums without a host round trip in between
-      int nb4 = (h->N / 4 + 255) / 256; if (nb4 > RED_BLOCKS) nb4 = RED_BLOCKS;
-      double2 *cs = tot + 8;
-      k_carrier_steps<<<1, 64, 0, h->st>>>(u_hi, u_lo, logrho, 4ull * (unsigned long long)nb4 * 256ull, cs);
-      k_mix4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, part);
-      k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 128), tot);
-      k_rotate4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, tot, o16v, oprev, part);
-      k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 144));
-      CHK(hipGetLastError());
-      if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
-      if (pre && !out_is_dev) CHK(hipMemcpyAsync(pre, h->d_pre, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
-      CHK(hipStreamSynchronize(h->st));
-      const volatile double *m = (const volatile double *)((char *)h->pin_hdr.h + 128);
-      const double dcr = m[0] / h->N, dci = m[1] / h->N;
-      res->dc_re = dcr; res->dc_im = dci; res->amplitude = hypot(dcr, dci); res->diffsumsq = m[2] / h->N;
-      return 0;
-    }
     // closed-form carrier per sample (small or unaligned blocks; ISEE3DSP_CARRIER_CLOSED=1)
     k_mix<<<nb, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, part);
     k_sum2<<<1, 256, 0, h->st>>>(part, nb, (double2 *)((char *)h->pin_hdr.d + 128));

@@ -53,13 +53,35 @@ static int c_mix(void *h, double cstep, pmdemod_mix *r, int16_t *out16) {
 }
 static void c_destroy(void *h) { cpu_t *c = h; free(c->buf); free(c->spec); free(c->lo); free(c); }
 
+/* the enqueue / collect halves (pmdemod_core.h): "enqueue" computes at once and parks the result in a side table keyed by
+ * the handle, "collect" hands it out; every call leaves a letter on stderr (B / E peak begin / end, M / N mix begin / end,
+ * S = a block sent back to the synchronous mix) so that the test can read the order the core issued them in.
+ * PMD_ASYNC_SYNCMIX=n: every n-th mix_begin answers 1. */
+static struct { void *h; pmdemod_peak pk; pmdemod_mix mx; } g_park[2];
+static int park_of(void *h) { for (int i = 0; i < 2; i++) if (g_park[i].h == h || !g_park[i].h) { g_park[i].h = h; return i; } return 0; }
+static long g_mixes;
+static int c_peak_begin(void *h, int a, int b) { fprintf(stderr, "B%d ", park_of(h)); return c_peak(h, a, b, &g_park[park_of(h)].pk); }
+static int c_peak_end(void *h, pmdemod_peak *o) { fprintf(stderr, "E%d ", park_of(h)); *o = g_park[park_of(h)].pk; return 0; }
+static int c_mix_begin(void *h, double cstep, int16_t *out16, int dev) {
+  (void)dev;
+  const int every = getenv("PMD_ASYNC_SYNCMIX") ? atoi(getenv("PMD_ASYNC_SYNCMIX")) : 0;
+  if (every && ++g_mixes % every == 0) { fprintf(stderr, "S%d ", park_of(h)); return 1; }
+  fprintf(stderr, "M%d ", park_of(h));
+  return c_mix(h, cstep, &g_park[park_of(h)].mx, out16);
+}
+static int c_mix_end(void *h, pmdemod_mix *r) { fprintf(stderr, "N%d ", park_of(h)); *r = g_park[park_of(h)].mx; return 0; }
+
 int main(int argc, char **argv) {
   pmdemod_opts o;
   int rc = pmdemod_parse_args(&o, argc, argv, stderr);
   if (rc) return rc;
   pmdemod_engine e = { c_create, c_dechirp, c_load, c_peak, c_mix, c_destroy };
+  if (getenv("PMD_ASYNC") && atoi(getenv("PMD_ASYNC"))) {
+    e.fft_peak_begin = c_peak_begin; e.fft_peak_end = c_peak_end; e.mix_begin = c_mix_begin; e.mix_end = c_mix_end;
+  }
   pmdemod_block_report rep[64]; int n = 0;
   rc = pmdemod_run(&o, &e, stdin, stdout, stderr, rep, 64, &n);
+  fprintf(stderr, "\n");
   for (int i = 0; i < n; i++) fprintf(stderr, "REPORT %d %.17g %.17g\n", rep[i].peak, rep[i].carrier_freq, rep[i].cn0);
   return rc;
 }

@@ -110,6 +110,45 @@ def test_pmdemod_host_logic_vs_oracle(pm_harness, name):
     assert np.allclose([float(r[2]) for r in rep], z[name + "/carrier_freq"], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("syncmix", ["0", "3"], ids=["all_async", "every_third_mix_synchronous"])
+@pytest.mark.parametrize("name", [str(n) for n in np.load(PG)["names"]])
+def test_pmdemod_two_handle_pipeline_same_output_and_order(pm_harness, name, syncmix):
+    """pmdemod_run_io with an engine that offers the enqueue / collect halves (pmd_*_begin / _end): for independent blocks
+    (-W 0) the core alternates two handles -- the next block's transform is enqueued (B) BEFORE this block's peak is
+    collected (E), a block's sums are collected (N) and the block handed on one iteration later -- and writes exactly the
+    bytes, peaks, carrier frequencies and C/N0 of the one-handle loop; with a search window (-W != 0: a block's search
+    depends on the previous block's lock) the halves are not used at all."""
+    z = np.load(PG)
+    args = _pm_args(z[name + "/cfg"])
+    runs = {}
+    for mode in ("0", "1"):
+        p = subprocess.run([pm_harness] + args, input=z[name + "/iq"].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           check=True, timeout=600, env=dict(os.environ, PMD_ASYNC=mode, PMD_ASYNC_SYNCMIX=syncmix))
+        rep = [l for l in p.stderr.decode().splitlines() if l.startswith("REPORT")]
+        trace = [l for l in p.stderr.decode().splitlines() if l[:1] in "BEMNS" and not l.startswith("REPORT")]
+        runs[mode] = (p.stdout, rep, " ".join(trace).split())
+    assert runs["1"][0] == runs["0"][0] and runs["1"][1] == runs["0"][1]
+    assert np.array_equal(np.frombuffer(runs["1"][0], np.int16), z[name + "/out"])
+    tr = runs["1"][2]
+    windowed = "-W" in args and float(args[args.index("-W") + 1]) != 0
+    nblk = len(runs["1"][1])
+    if windowed or nblk == 0:
+        assert tr == [] and runs["0"][2] == []
+        return
+    assert runs["0"][2] == []
+    # block k lives on handle k & 1; order: B0 [B1 E0 M0] [B0 E1 N0 M1] ... ; the last block is collected in its own iteration
+    assert tr[0] == "B0" and tr.count("B0") + tr.count("B1") == nblk and tr.count("E0") + tr.count("E1") == nblk
+    for k in range(nblk - 1):
+        cur, nxt = k & 1, (k + 1) & 1
+        assert tr.index("B%d" % nxt, 0) >= 0
+        ib = [i for i, t in enumerate(tr) if t == "B%d" % nxt][(k + 1) // 2]        # block k+1's transform enqueued ...
+        ie = [i for i, t in enumerate(tr) if t == "E%d" % cur][k // 2]              # ... before block k's peak is collected
+        assert ib < ie, (k, tr)
+    mixes = [t for t in tr if t[0] in "MS"]
+    assert len(mixes) == nblk and (syncmix == "0") == all(t[0] == "M" for t in mixes)
+    assert tr.count("N0") + tr.count("N1") == sum(t[0] == "M" for t in mixes)
+
+
 def test_oracle_fft_vs_numpy():
     rng = np.random.default_rng(5)
     for n in (16, 1024, 1 << 15):
