@@ -520,7 +520,9 @@ def main():
                     help="> 1: cut ONE capture into this many overlapped segments over all ranks (configs[4])")
     ap.add_argument("--chain-warm-blocks", type=int, default=7)
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] record (10 MS/s, 64 overlapped segments)")
-    ap.add_argument("--stress-blocks", type=int, default=64)
+    ap.add_argument("--stress-blocks", type=int, default=128,
+                    help="blocks of 2^23 samples in the stress capture (64 B: every one of the 64 segments owns B blocks and carries 7 "
+                         "warm-up blocks; B = 2: 107 s of signal, 4.3 GB)")
     ap.add_argument("--stress-segments", type=int, default=64)
     ap.add_argument("--dry-ranks", action="store_true",
                     help="no device work: every rank runs a stand-in step through the same launcher / sharding / fence / MAX "
