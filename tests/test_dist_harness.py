@@ -140,3 +140,30 @@ def test_bench_under_torchrun_is_not_started_twice_and_checks_world_size():
     p, line = _bench_lines([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-ranks", "--steps", "1"],
                            env={})
     assert p.returncode == 0 and len(line) == 1 and json.loads(line[0])["n_gpus"] == 1
+
+
+def test_bench_record_helpers_without_a_device():
+    """bench.py's pure helpers: the chain roofline object built from the committed PMC record (bytes per IQ sample and
+    stage x samples / step time against 8 TB/s, the SURVEY 8(d) algorithmic figure beside it) and the host description of
+    the CPU baselines.  No device, no timing: the schema and the arithmetic."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_chain.json")))
+    for cfg in pmc["configs"]:
+        fs, nsamp, dt = cfg["samprate"], 15_000_000, 0.03
+        r = bench.chain_roofline(fs, cfg["binsize"], nsamp, dt, [6.0, 8.0, 26.0])
+        total = sum(cfg["hbm_bytes_per_sample"].values())
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+        assert abs(r["traffic"] - total * nsamp) <= 1 and abs(r["achieved"] - total * nsamp / dt / 1e9) < 0.1
+        assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+        assert abs(r["algorithmic_bytes_per_sample"] - (8 + 1024.545058 / fs * 17301504)) < 0.1
+        assert set(r["stages"]) == {"pmdemod", "symdemod", "viterbi", "what"}
+        assert r["stages"]["viterbi"]["hbm_bytes"] == int(cfg["hbm_bytes_per_sample"]["viterbi"] * nsamp)
+    assert bench.chain_roofline(123456.0, 1.0, 1000, 1.0) is None            # no PMC record for that rate: no invented number
+    h = bench.host_info()
+    assert h["nproc"] >= 1 and h["nproc_allowed"] >= 1 and isinstance(h["cpu_model"], str) and isinstance(h["avx2"], bool)
+    with bench.pinned_to_one_core() as pin:
+        assert not pin.ok or os.sched_getaffinity(0) == {pin.core}
+    assert len(os.sched_getaffinity(0)) == h["nproc_allowed"]
