@@ -269,6 +269,7 @@ DSP_SYMBOLS = [
     "pmd_create", "pmd_destroy", "pmd_set_dechirp", "pmd_load", "pmd_fft_peak", "pmd_mix_quantise",
     "pmd_fft_peak_begin", "pmd_fft_peak_end", "pmd_mix_begin", "pmd_mix_end",
     "pmd_get_spectrum",
+    "pmd_last_peak_path",
     "isync_create", "isync_destroy", "isync_set_vector", "isync_search",
 ]
 
@@ -404,6 +405,7 @@ def dsp_lib():
     L.pmd_fft_peak.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(PmdPeak)]
     L.pmd_mix_quantise.argtypes = [C.c_void_p, C.c_double, C.POINTER(PmdMix), C.c_void_p, C.c_void_p, C.c_int]
     L.pmd_get_spectrum.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmd_last_peak_path.argtypes = [C.c_void_p]
     L.isync_create.restype = C.c_void_p
     L.isync_create.argtypes = [C.c_int]
     L.isync_destroy.argtypes = [C.c_void_p]
@@ -506,6 +508,10 @@ class PmDemodEngine:
         if self.L.pmd_fft_peak(self.h, firstbin, self.N if lastbin is None else lastbin, C.byref(pk)) != 0:
             raise RuntimeError("pmd_fft_peak: " + dsp_error())
         return pk
+
+    def last_peak_path(self):
+        """0 double transform, 1 single-precision search + exact bins, 2 search, then fallen back to the double transform."""
+        return int(self.L.pmd_last_peak_path(self.h))
 
     def spectrum(self):
         out = np.zeros(self.N, dtype=np.complex128)

@@ -789,6 +789,10 @@ struct Pmd {
   void *d_red; size_t red_cap;           // reduction scratch
   hipEvent_t ev_peak, ev_mix;            // behind the transform + peak kernels / behind the two spin-down passes (the *_begin / *_end calls)
   void *d_peakpart; size_t peakpart_cap; // one peak record per workgroup of the last FFT pass
+  void *d_dft; size_t dft_cap;           // search transform: DftAsk + the partial sums of k_dft_bins
+  int ask_first, ask_last;               // the bin range of the peak search in flight (a fall-back repeats it)
+  int spec_valid;                        // spec holds the double transform of the current block (pmd_get_spectrum)
+  int last_path;                         // pmd_last_peak_path
   int16_t *d_out16; double *d_pre;
   int have_lo;
   Pin pin_hdr;                           // peak record @0, spin-down sum @128, variance sum @144: written by the kernels
@@ -904,26 +908,36 @@ __global__ __launch_bounds__(256) void k_fft_radix(const double2 *__restrict__ x
 #ifndef FFT1_ABL
 #define FFT1_ABL 0        // bench builds only, first pass: 1 no global loads, 2 no twiddle walk, 4 no stores, 8 no register DFTs
 #endif
-template <int R> __device__ __forceinline__ void dft_regs(double2 (&a)[R]) {     // radix-2 DIF network; a[brev(k)] = X[k]
+// the passes exist in two element types: double2 (every transform whose values are used) and float2 (pmdemod's SEARCH
+// transform, which only has to find the bins worth evaluating exactly: pmd_fft_peak_begin)
+template <typename V> struct VecOf;
+template <> struct VecOf<double2> { using T = double; };
+template <> struct VecOf<float2>  { using T = float; };
+template <typename V> __device__ __forceinline__ V mkv(typename VecOf<V>::T x, typename VecOf<V>::T y) { V r; r.x = x; r.y = y; return r; }
+template <typename V> __device__ __forceinline__ V vec_as(const double2 w) { return mkv<V>((typename VecOf<V>::T)w.x, (typename VecOf<V>::T)w.y); }
+template <typename V> __device__ __forceinline__ double2 as_d2(const V w) { return make_double2((double)w.x, (double)w.y); }
+template <int R, typename V> __device__ __forceinline__ void dft_regs(V (&a)[R]) {     // radix-2 DIF network; a[brev(k)] = X[k]
+  using T = typename VecOf<V>::T;
 #pragma unroll
   for (int span = R / 2; span >= 1; span >>= 1) {
 #pragma unroll
     for (int base = 0; base < R; base += 2 * span) {
 #pragma unroll
       for (int m = 0; m < span; m++) {
-        const double2 u = a[base + m], v = a[base + m + span];
-        a[base + m] = make_double2(u.x + v.x, u.y + v.y);
-        const double dr = u.x - v.x, di = u.y - v.y;
+        const V u = a[base + m], v = a[base + m + span];
+        a[base + m] = mkv<V>(u.x + v.x, u.y + v.y);
+        const T dr = u.x - v.x, di = u.y - v.y;
         const int e = m * (8 / span);                    // exponent of omega_16
-        if (e == 0) a[base + m + span] = make_double2(dr, di);
-        else if (e == 4) a[base + m + span] = make_double2(di, -dr);          // * (-j)
-        else { const double c = k_c16[e], sn = k_s16[e];
-               a[base + m + span] = make_double2(dr * c + di * sn, di * c - dr * sn); }   // * (c - j sn)
+        if (e == 0) a[base + m + span] = mkv<V>(dr, di);
+        else if (e == 4) a[base + m + span] = mkv<V>(di, -dr);          // * (-j)
+        else { const T c = (T)k_c16[e], sn = (T)k_s16[e];
+               a[base + m + span] = mkv<V>(dr * c + di * sn, di * c - dr * sn); }   // * (c - j sn)
       }
     }
   }
 }
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // sample i of the block as pmdemod.c:209-229 forms it (+ :237-243 with a de-chirp table)
 __device__ __forceinline__ double2 iq_sample(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int i, int flip) {
   const short2 v = iq[i];
@@ -948,25 +962,33 @@ constexpr int lg2c(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 #define SRC_IQ 1
 #define SRC_REAL16 2
 #define SRC_CONJPROD 3
-struct PeakRec { double e; int idx; int pad; };
-__device__ __forceinline__ bool peak_better(double e, int i, double be, int bi) {
+struct PeakRec { double e; int idx; int near; };    // near: only written by the search transform's PEAK pass
+template <typename T> __device__ __forceinline__ bool peak_better(T e, int i, T be, int bi) {
   return e > be || (e == be && i > bi);     // ">=" while scanning upward == last maximum wins
 }
 // PEAK (the last pass of pmdemod's transform): the |X|^2 arg-max of pmdemod.c:255-279 over bins [pfirst, plast) rides on
 // the pass that produces the bins -- one PeakRec per workgroup -- instead of reading the 16 N bytes of spectrum again
 // FTC: columns per workgroup (FT = 16 everywhere except where the first pass reads 2- or 4-byte samples: there 32 columns
 // make the read runs 128 bytes -- a whole cache line per row and tile -- instead of 64)
-template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT>
+// V = float2 (the search transform): a PEAK pass stores NO spectrum -- its per-workgroup record also says how many of the
+// workgroup's bins lie within PEAK_NEAR of the workgroup's maximum (PeakRec::near), which is what k_peak_cands needs to know
+// that the records hold EVERY bin near the global maximum.
+#define PEAK_NEAR 9.765625e-4      // 2^-10: relative distance in |X|^2 inside which single precision may have swapped two bins
+                                   // (its error against the largest bin is ~1e-6: three orders of margin)
+template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT, typename V = double2>
 __global__ __launch_bounds__(FTC * (PassShape<LG>::R1 > PassShape<LG>::R2 ? PassShape<LG>::R1 : PassShape<LG>::R2))
-void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip,
-                double2 *__restrict__ y, const double2 *__restrict__ twA, const double2 *__restrict__ twB,
+void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip,
+                V *__restrict__ y, const double2 *__restrict__ twA, const double2 *__restrict__ twB,
                 const double2 *__restrict__ twR, int N, int s, int pfirst = 0, int plast = 0, PeakRec *__restrict__ ppart = nullptr) {
+  using T = typename VecOf<V>::T;
+  constexpr bool SEARCH = std::is_same<V, float2>::value;
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2;
-  extern __shared__ double2 Z[];                          // [R2][R1][FTC]
+  extern __shared__ double2 Zraw[];                       // [R2][R1][FTC]
+  V *Z = reinterpret_cast<V *>(Zraw);
   const int c = threadIdx.x & (FTC - 1), r = threadIdx.x / FTC;
   const int t = blockIdx.x * FTC + c, stride = N / R;
   if (r < R2) {                                           // ---- step 1, thread (c, a = r)
-    double2 v[R1];
+    V v[R1];
     if constexpr (SRC == SRC_IQ && !(FIRST && (FFT1_ABL & 1))) {
       // all R1 loads first, then the conversions: written per sample (iq_sample: load, test `lo`, convert) the compiler
       // waited for every load before issuing the next -- sixteen dependent memory round trips, 45 of the pass's 74 us
@@ -981,19 +1003,19 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
         for (int b = 0; b < R1; b++) {
           const double x = flip ? (double)raw[b].y : (double)raw[b].x, y = flip ? (double)raw[b].x : (double)raw[b].y;
           const double pr = l[b].x, pi = -l[b].y;
-          v[b] = make_double2(x * pr - y * pi, x * pi + y * pr);
+          v[b] = mkv<V>((T)(x * pr - y * pi), (T)(x * pi + y * pr));
         }
       } else {
 #pragma unroll
         for (int b = 0; b < R1; b++)
-          v[b] = make_double2(flip ? (double)raw[b].y : (double)raw[b].x, flip ? (double)raw[b].x : (double)raw[b].y);
+          v[b] = mkv<V>(flip ? (T)raw[b].y : (T)raw[b].x, flip ? (T)raw[b].x : (T)raw[b].y);
       }
     } else if constexpr (SRC == SRC_CONJPROD) {             // conj(x[i] * v[i]); both operand sets loaded before the first product
       double2 xa[R1], va[R1];
 #pragma unroll
-      for (int b = 0; b < R1; b++) { xa[b] = x[t + (r + R2 * b) * stride]; va[b] = lo[t + (r + R2 * b) * stride]; }
+      for (int b = 0; b < R1; b++) { xa[b] = as_d2(x[t + (r + R2 * b) * stride]); va[b] = lo[t + (r + R2 * b) * stride]; }
 #pragma unroll
-      for (int b = 0; b < R1; b++) { const double2 p = cmul(xa[b], va[b]); v[b] = make_double2(p.x, -p.y); }
+      for (int b = 0; b < R1; b++) { const double2 p = cmul(xa[b], va[b]); v[b] = mkv<V>((T)p.x, (T)-p.y); }
     } else if constexpr (SRC == SRC_REAL16) {               // int16 real samples, zero beyond flip = nvalid (icesync.c:151-163)
       int16_t ra[R1];
 #pragma unroll
@@ -1002,45 +1024,50 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
         ra[b] = reinterpret_cast<const int16_t *>(iq)[i < flip ? i : 0];       // always a load (no branch), masked below
       }
 #pragma unroll
-      for (int b = 0; b < R1; b++) v[b] = make_double2(t + (r + R2 * b) * stride < flip ? (double)ra[b] : 0.0, 0.0);
+      for (int b = 0; b < R1; b++) v[b] = mkv<V>(t + (r + R2 * b) * stride < flip ? (T)ra[b] : (T)0, (T)0);
     } else
 #pragma unroll
     for (int b = 0; b < R1; b++) {
       const int i = t + (r + R2 * b) * stride;
-      if constexpr (FIRST && (FFT1_ABL & 1)) v[b] = make_double2((double)(i & 1023), (double)(i >> 10));
-      else if constexpr (SRC == SRC_IQ) v[b] = iq_sample(iq, lo, i, flip);
-      else if constexpr (SRC == SRC_REAL16) v[b] = make_double2(i < flip ? (double)reinterpret_cast<const int16_t *>(iq)[i] : 0.0, 0.0);   // flip = nvalid
-      else if constexpr (SRC == SRC_CONJPROD) { const double2 p = cmul(x[i], lo[i]); v[b] = make_double2(p.x, -p.y); }
+      if constexpr (FIRST && (FFT1_ABL & 1)) v[b] = mkv<V>((T)(i & 1023), (T)(i >> 10));
+      else if constexpr (SRC == SRC_IQ) v[b] = vec_as<V>(iq_sample(iq, lo, i, flip));
+      else if constexpr (SRC == SRC_REAL16) v[b] = mkv<V>(i < flip ? (T)reinterpret_cast<const int16_t *>(iq)[i] : (T)0, (T)0);   // flip = nvalid
+      else if constexpr (SRC == SRC_CONJPROD) { const double2 p = cmul(as_d2(x[i]), lo[i]); v[b] = mkv<V>((T)p.x, (T)-p.y); }
       else v[b] = x[i];
     }
     if constexpr (!(FIRST && (FFT1_ABL & 8))) dft_regs<R1>(v);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) {
-      double2 val = v[brev(k1, lg2c(R1))];
-      if (k1 > 0) val = cmul(val, twR[(r * k1) * (256 / R)]);      // W_R^(a k1); a = 0 reads W^0 = 1 exactly
+      V val = v[brev(k1, lg2c(R1))];
+      if (k1 > 0) val = cmul(val, vec_as<V>(twR[(r * k1) * (256 / R)]));      // W_R^(a k1); a = 0 reads W^0 = 1 exactly
       Z[(r * R1 + k1) * FTC + c] = val;
     }
   }
   __syncthreads();
-  double be = -1.0; int bi = -1;
-  double2 u_first[FIRST ? R2 : 1];                        // a first stage's results (see the transposed store below)
+  T be = (T)-1; int bi = -1;
+  T ef[(PEAK && SEARCH) ? R2 : 1];                        // search transform: the energies of this thread's bins (-1: outside [pfirst, plast))
+  if constexpr (PEAK && SEARCH) {
+#pragma unroll
+    for (int k2 = 0; k2 < R2; k2++) ef[k2] = (T)-1;
+  }
+  V u_first[FIRST ? R2 : 1];                              // a first stage's results (see the transposed store below)
   if (r < R1) {                                           // ---- step 2, thread (c, k1 = r)
-    double2 u[R2];
+    V u[R2];
 #pragma unroll
     for (int a = 0; a < R2; a++) u[a] = Z[(a * R1 + r) * FTC + c];
     if constexpr (!(FIRST && (FFT1_ABL & 8))) dft_regs<R2>(u);
     const int q = t & (s - 1), ps = t - q;
-    double2 *__restrict__ out = y + q + (size_t)R * ps;
+    V *__restrict__ out = y + q + (size_t)R * ps;
     // stage twiddle W_N^(ps k), k = k1 + R1 k2 (ps k < N), from the two-level table W_N^(4096 h) * W_N^l.  In the first
     // stage ps = t differs from lane to lane and every lookup is a 64-address gather: there the thread looks up only
     // W^(ps k1) and the step W^(ps R1) and walks k2 by multiplication (<= 15 products: ~1e-15 relative); later stages
     // have ONE ps per tile, their lookups are broadcasts and stay direct.
     // W_N^idx = twB[idx & 4095] (* twA[idx >> 12] when that is not W^0).  In the first stage both table words of both
     // lookups are loaded before the first use (four loads in flight instead of four dependent round trips).
-    auto tw2_sel = [&](unsigned idx, double2 wb, double2 wa) { return (idx >> 12) ? cmul(wa, wb) : wb; };
+    auto tw2_sel = [&](unsigned idx, double2 wb, double2 wa) { return vec_as<V>((idx >> 12) ? cmul(wa, wb) : wb); };
     if constexpr (FIRST) {
       const bool walk = !(FFT1_ABL & 2);                    // first stage <=> s == 1
-      double2 wk = make_double2(1.0, 0.0), wstep = wk;
+      V wk = mkv<V>((T)1, (T)0), wstep = wk;
       if (walk) {
         const unsigned i1 = (unsigned)ps * (unsigned)r, i2 = (unsigned)ps * (unsigned)R1;
         const double2 b1 = twB[i1 & 4095u], a1 = twA[i1 >> 12], b2 = twB[i2 & 4095u], a2 = twA[i2 >> 12];
@@ -1049,7 +1076,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++) {
         const int k = r + R1 * k2;
-        double2 val = u[brev(k2, lg2c(R2))];
+        V val = u[brev(k2, lg2c(R2))];
         if (walk && ps != 0 && k != 0) val = cmul(val, wk);
         if (walk) wk = cmul(wk, wstep);
         u_first[k2] = val;                                  // parked: leaves through the LDS transpose below
@@ -1062,7 +1089,7 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
 #ifndef FFT_LOOKUP_ALL
 #define FFT_LOOKUP_ALL 0
 #endif
-      double2 wk = make_double2(1.0, 0.0), wstep = wk;
+      V wk = mkv<V>((T)1, (T)0), wstep = wk;
       if (!FFT_LOOKUP_ALL) {
         const unsigned i1 = (unsigned)ps * (unsigned)r, i2 = (unsigned)ps * (unsigned)R1;
         const double2 b1 = twB[i1 & 4095u], a1 = twA[i1 >> 12], b2 = twB[i2 & 4095u], a2 = twA[i2 >> 12];
@@ -1071,21 +1098,24 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++) {
         const int k = r + R1 * k2;
-        double2 val = u[brev(k2, lg2c(R2))];
+        V val = u[brev(k2, lg2c(R2))];
         if (ps != 0 && k != 0) {
           if (FFT_LOOKUP_ALL) {
             const unsigned idx = (unsigned)ps * (unsigned)k;
             double2 w = twB[idx & 4095u];
             if (idx >> 12) w = cmul(twA[idx >> 12], w);
-            val = cmul(val, w);
+            val = cmul(val, vec_as<V>(w));
           } else val = cmul(val, wk);
         }
         if (!FFT_LOOKUP_ALL) wk = cmul(wk, wstep);
-        out[(size_t)k * s] = val;
+        if constexpr (!(PEAK && SEARCH)) out[(size_t)k * s] = val;
         if constexpr (PEAK) {
           const int i = q + R * ps + k * s;                 // the bin this value is (the last pass: N fits an int)
-          const double e = val.x * val.x + val.y * val.y;
-          if (i >= pfirst && i < plast && peak_better(e, i, be, bi)) { be = e; bi = i; }
+          const T e = val.x * val.x + val.y * val.y;
+          if (i >= pfirst && i < plast) {
+            if constexpr (SEARCH) ef[k2] = e;
+            if (peak_better(e, i, be, bi)) { be = e; bi = i; }
+          }
         }
       }
     }
@@ -1103,11 +1133,11 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
       for (int k2 = 0; k2 < R2; k2++) Z[c * (R + 1) + r + R1 * k2] = u_first[k2];
     }
     __syncthreads();
-    double2 *__restrict__ blk = y + (size_t)R * ((size_t)blockIdx.x * FTC);
+    V *__restrict__ blk = y + (size_t)R * ((size_t)blockIdx.x * FTC);
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < FTC * R; idx += TH) {
-      const double2 o = Z[(idx / R) * (R + 1) + (idx % R)];
-      if constexpr (FFT1_ABL & 4) { if (o.x == 1.2345e300) blk[idx] = o; }
+      const V o = Z[(idx / R) * (R + 1) + (idx % R)];
+      if constexpr (FFT1_ABL & 4) { if (o.x == (T)1.2345e30) blk[idx] = o; }
       else blk[idx] = o;
     }
   }
@@ -1115,16 +1145,33 @@ void k_fft_pass(const double2 *__restrict__ x, const short2 *__restrict__ iq, co
     constexpr int TH = FTC * (R1 > R2 ? R1 : R2), NW = (TH + 63) / 64;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const double oe = __shfl_xor(be, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      const T oe = __shfl_xor(be, o, 64); const int oi = __shfl_xor(bi, o, 64);
       if (peak_better(oe, oi, be, bi)) { be = oe; bi = oi; }
     }
     __syncthreads();                                        // every thread has read its part of Z
-    PeakRec *ws = reinterpret_cast<PeakRec *>(Z);
-    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6].e = be; ws[threadIdx.x >> 6].idx = bi; }
+    PeakRec *ws = reinterpret_cast<PeakRec *>(Zraw);
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6].e = (double)be; ws[threadIdx.x >> 6].idx = bi; }
     __syncthreads();
+    int near = 0;
+    if constexpr (SEARCH) {
+      // how many of the workgroup's bins lie within PEAK_NEAR of ITS maximum (the maximum itself included)
+      double wm = ws[0].e;
+      for (int w = 1; w < NW; w++) wm = ws[w].e > wm ? ws[w].e : wm;
+      const T lim = (T)(wm * (1.0 - PEAK_NEAR));
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) near += (ef[k2] >= (T)0 && ef[k2] >= lim) ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) near += __shfl_xor(near, o, 64);
+      int *wn = reinterpret_cast<int *>(ws + NW);
+      if ((threadIdx.x & 63) == 0) wn[threadIdx.x >> 6] = near;
+      __syncthreads();
+      near = 0;
+      for (int w = 0; w < NW; w++) near += wn[w];
+    }
     if (threadIdx.x == 0) {
-      for (int w = 1; w < NW; w++) if (peak_better(ws[w].e, ws[w].idx, be, bi)) { be = ws[w].e; bi = ws[w].idx; }
-      ppart[blockIdx.x].e = be; ppart[blockIdx.x].idx = bi;
+      double fe = ws[0].e; int fi = ws[0].idx;
+      for (int w = 1; w < NW; w++) if (peak_better(ws[w].e, ws[w].idx, fe, fi)) { fe = ws[w].e; fi = ws[w].idx; }
+      ppart[blockIdx.x].e = fe; ppart[blockIdx.x].idx = fi; ppart[blockIdx.x].near = near;
     }
   }
 }
@@ -1353,15 +1400,152 @@ __global__ __launch_bounds__(256) void k_rotate4(const short2 *__restrict__ iq, 
   if (threadIdx.x == 0) part[blockIdx.x] = make_double2(ws[0] + ws[1] + ws[2] + ws[3], 0.0);
 }
 
+// ---- pmdemod's peak search through a SINGLE-precision transform + exact bins ------------------------------------------
+// pmdemod.c:253-318 needs three numbers of the 2^23-point spectrum: the largest bin (last one on ties) and its two
+// neighbours.  The transform that finds it need not be the one that evaluates it: k_fft_pass<..., float2> moves half the
+// bytes per pass and its last pass stores nothing (302 MB instead of 704 MB of traffic at 2^23), leaving one record per
+// workgroup; k_peak_cands turns the records into the list of bins whose single-precision energy lies within PEAK_NEAR of
+// the maximum (normally one); k_dft_bins evaluates X[k-1], X[k], X[k+1] of every listed bin from the int16 block in DOUBLE
+// precision (stepped twiddles as k_mix4's carriers, seeded from the transform's own table of W_N^m);
+// k_dft_final adds the partial sums in a fixed order and applies pmdemod.c's arg-max rule to the exact energies.  What
+// leaves is at least as accurate as the double transform's bins (a direct sum: ~1e-16 sqrt(N) relative).  The list is
+// COMPLETE by construction: a bin within PEAK_NEAR of the global maximum is within PEAK_NEAR of its own workgroup's maximum,
+// and a workgroup that holds two such bins says so (PeakRec::near > 1).  Then -- or with more than DFT_KMAX candidates, or
+// nothing positive (an all-zero block: every bin ties) -- status = 1 and pmd_fft_peak_end runs the double transform.
+#define DFT_KMAX 4
+struct DftAsk { int status, ncand; int bins[3 * DFT_KMAX]; };        // per candidate: k - 1, k, k + 1 (mod N)
+__global__ __launch_bounds__(256) void k_peak_cands(const PeakRec *__restrict__ part, int nparts, int N, int force_fallback,
+                                                    DftAsk *__restrict__ ask) {
+  __shared__ PeakRec ws[256];
+  __shared__ int s_n, s_amb, s_bins[DFT_KMAX];
+  double be = -1.0; int bi = -1;
+  for (int p = threadIdx.x; p < nparts; p += 256) if (peak_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
+  ws[threadIdx.x].e = be; ws[threadIdx.x].idx = bi;
+  if (threadIdx.x == 0) { s_n = 0; s_amb = 0; }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o && peak_better(ws[threadIdx.x + o].e, ws[threadIdx.x + o].idx, ws[threadIdx.x].e, ws[threadIdx.x].idx))
+      ws[threadIdx.x] = ws[threadIdx.x + o];
+    __syncthreads();
+  }
+  be = ws[0].e; bi = ws[0].idx;
+  const double lim = be * (1.0 - PEAK_NEAR);
+  if (bi >= 0 && be > 0.0)
+    for (int p = threadIdx.x; p < nparts; p += 256)
+      if (part[p].idx >= 0 && part[p].e >= lim) {
+        const int slot = atomicAdd(&s_n, 1);
+        if (slot < DFT_KMAX) s_bins[slot] = part[p].idx;
+        if (part[p].near > 1) s_amb = 1;
+      }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const bool ok = bi >= 0 && be > 0.0 && s_n >= 1 && s_n <= DFT_KMAX && !s_amb && !force_fallback;
+  ask->status = ok ? 0 : 1; ask->ncand = ok ? s_n : 0;
+  for (int j = 0; ok && j < s_n; j++) {
+    const int k = s_bins[j];
+    ask->bins[3 * j] = (N + k - 1) % N; ask->bins[3 * j + 1] = k; ask->bins[3 * j + 2] = (k + 1) % N;
+  }
+}
+// X[bin] = sum_n sample_n e^{-2 pi j bin n / N} for the three bins of candidate blockIdx.y; one partial sum per workgroup
+// (the twiddles W_N^m come from the transform's own two-level table -- W_N^(4096 h) * W_N^l, both entries correctly rounded
+// -- instead of a sincospi per seed: the first form of this kernel spent two thirds of its 35 us on its 9 sincospi per thread)
+__device__ __forceinline__ double2 tw_at(const double2 *__restrict__ twA, const double2 *__restrict__ twB, unsigned m) {
+  const double2 wb = twB[m & 4095u], wa = twA[m >> 12];
+  return (m >> 12) ? cmul(wa, wb) : wb;
+}
+__global__ __launch_bounds__(256) void k_dft_bins(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
+                                                  const double2 *__restrict__ twA, const double2 *__restrict__ twB,
+                                                  const DftAsk *__restrict__ ask, double2 *__restrict__ part) {
+  if (ask->status != 0 || (int)blockIdx.y >= ask->ncand) return;
+  __shared__ double2 sw[3][4];
+  __shared__ double2 wsum[3][4];
+  const int T = gridDim.x * 256, ng = N >> 2;
+  const unsigned long long nm = (unsigned long long)N - 1ull;
+  if (threadIdx.x < 12) {
+    const int b = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const unsigned long long bin = (unsigned long long)ask->bins[3 * blockIdx.y + b];
+    sw[b][j] = tw_at(twA, twB, (unsigned)((bin * (j < 3 ? (unsigned long long)(j + 1) : 4ull * (unsigned long long)T)) & nm));
+  }
+  __syncthreads();
+  unsigned long long u[3];
+  double2 w1[3], w2[3], w3[3], wT[3], c0[3];
+  double sr[3] = {0, 0, 0}, si[3] = {0, 0, 0};
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    u[b] = (unsigned long long)ask->bins[3 * blockIdx.y + b];
+    w1[b] = sw[b][0]; w2[b] = sw[b][1]; w3[b] = sw[b][2]; wT[b] = sw[b][3];
+    c0[b] = make_double2(1.0, 0.0);
+  }
+  int it = 0;
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += T, it++) {
+    double2 v[4];
+    iq_group4(iq, lo, g, flip, v);
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      c0[b] = (it & (CARRIER_RESEED - 1)) == 0 ? tw_at(twA, twB, (unsigned)((u[b] * 4ull * (unsigned long long)g) & nm)) : cmul(c0[b], wT[b]);
+      const double2 c[4] = {c0[b], cmul(c0[b], w1[b]), cmul(c0[b], w2[b]), cmul(c0[b], w3[b])};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sr[b] += v[k].x * c[k].x - v[k].y * c[k].y;
+        si[b] += v[k].x * c[k].y + v[k].y * c[k].x;
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sr[b] += __shfl_xor(sr[b], o, 64); si[b] += __shfl_xor(si[b], o, 64); }
+    if ((threadIdx.x & 63) == 0) wsum[b][threadIdx.x >> 6] = make_double2(sr[b], si[b]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int b = threadIdx.x;
+    part[((size_t)blockIdx.y * 3 + b) * gridDim.x + blockIdx.x] =
+      make_double2(wsum[b][0].x + wsum[b][1].x + wsum[b][2].x + wsum[b][3].x, wsum[b][0].y + wsum[b][1].y + wsum[b][2].y + wsum[b][3].y);
+  }
+}
+// the partial sums in a fixed order; pmdemod.c:255-279's rule (last maximum wins) on the exact energies; out->peak = -2 tells
+// pmd_fft_peak_end to run the double transform
+__global__ __launch_bounds__(256) void k_dft_final(const double2 *__restrict__ part, int nb, const DftAsk *__restrict__ ask, pmd_peak *out) {
+  __shared__ double2 ws[256];
+  __shared__ double2 X[3 * DFT_KMAX];
+  if (ask->status != 0) { if (threadIdx.x == 0) out->peak = -2; return; }
+  const int nc = ask->ncand;
+  for (int v = 0; v < 3 * nc; v++) {
+    double2 a = make_double2(0.0, 0.0);
+    for (int p = threadIdx.x; p < nb; p += 256) { const double2 q = part[(size_t)v * nb + p]; a.x += q.x; a.y += q.y; }
+    ws[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) { ws[threadIdx.x].x += ws[threadIdx.x + o].x; ws[threadIdx.x].y += ws[threadIdx.x + o].y; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) X[v] = ws[0];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  double be = -1.0; int bi = -1, bc = 0;
+  for (int c = 0; c < nc; c++) {
+    const double2 x = X[3 * c + 1];
+    const double e = x.x * x.x + x.y * x.y;
+    if (peak_better(e, ask->bins[3 * c + 1], be, bi)) { be = e; bi = ask->bins[3 * c + 1]; bc = c; }
+  }
+  out->peak = bi; out->maxenergy = be;
+  out->peak_re = X[3 * bc + 1].x; out->peak_im = X[3 * bc + 1].y;
+  out->next_re = X[3 * bc + 2].x; out->next_im = X[3 * bc + 2].y;
+  out->prev_re = X[3 * bc].x;     out->prev_im = X[3 * bc].y;
+}
+
 // what a transform needs besides its data: the twiddle tables of its size and a stream
 struct FftCtx { int N, logN; const double2 *twA, *twB, *twR; hipStream_t st; };
-struct FftSrc { const double2 *x; const void *i16; const double2 *aux; int iparam; };   // see SRC_*: (x) | (iq, lo, flip) | (samples, -, nvalid) | (x, v)
+struct FftSrc { const void *x; const void *i16; const double2 *aux; int iparam; };   // see SRC_*: (x) | (iq, lo, flip) | (samples, -, nvalid) | (x, v); x: elements of the transform's type
 
 struct PeakAsk { int first, last; PeakRec *part; int nparts; };     // nparts: set by the launch (one per workgroup)
-template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT>
-static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
+template <int LG, int SRC, bool FIRST, bool PEAK = false, int FTC = FT, typename V = double2>
+static int launch_pass(const FftCtx &c, const FftSrc &in, V *dst, int s, PeakAsk *pk = nullptr) {
   constexpr int R1 = PassShape<LG>::R1, R2 = PassShape<LG>::R2, R = R1 * R2, TH = FTC * (R1 > R2 ? R1 : R2);
-  size_t lds = sizeof(double2) * (FIRST ? R + 1 : R) * FTC;            // a first stage re-uses the tile as its padded output image
+  size_t lds = sizeof(V) * (FIRST ? R + 1 : R) * FTC;                  // a first stage re-uses the tile as its padded output image
+  if (PEAK && lds < 512) lds = 512;                                    // (the peak records of the waves)
   // ISEE3DSP_FFT_LDS_KB=n: every pass ASKS for n KiB of LDS (it uses what it needs).  With 88 exactly one FFT workgroup fits a
   // CU and 72 KiB stay free: a Viterbi workgroup (68.6 KiB) always finds room beside it, whereas two 64 KiB FFT workgroups
   // on a CU make the 256-workgroup ACS launch wait for one of them to finish
@@ -1374,37 +1558,47 @@ static int launch_pass(const FftCtx &c, const FftSrc &in, double2 *dst, int s, P
   if (hipGetDevice(&dev) != hipSuccess) return -1;
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST, PEAK, FTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_fft_pass<LG, SRC, FIRST, PEAK, FTC, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   if constexpr (PEAK) {
     pk->nparts = c.N / R / FTC;
-    k_fft_pass<LG, SRC, FIRST, true, FTC><<<c.N / R / FTC, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s,
-                                                                            pk->first, pk->last, pk->part);
+    k_fft_pass<LG, SRC, FIRST, true, FTC, V><<<c.N / R / FTC, TH, lds, c.st>>>((const V *)in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s,
+                                                                               pk->first, pk->last, pk->part);
   } else
-    k_fft_pass<LG, SRC, FIRST, false, FTC><<<c.N / R / FTC, TH, lds, c.st>>>(in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
+    k_fft_pass<LG, SRC, FIRST, false, FTC, V><<<c.N / R / FTC, TH, lds, c.st>>>((const V *)in.x, (const short2 *)in.i16, in.aux, in.iparam, dst, c.twA, c.twB, c.twR, c.N, s);
   return 0;
 }
-template <int SRC, bool FIRST, bool PEAK = false>
-static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, double2 *dst, int s, PeakAsk *pk = nullptr) {
+template <int SRC, bool FIRST, bool PEAK = false, typename V = double2>
+static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, V *dst, int s, PeakAsk *pk = nullptr) {
+  // the search transform (8-byte elements): 32 columns everywhere -- 256-byte runs, 64 KiB tiles at radix 256
+  if constexpr (std::is_same<V, float2>::value) {
+    switch (lg) {
+    case 5: return launch_pass<5, SRC, FIRST, PEAK, 32, V>(c, in, dst, s, pk);
+    case 6: return launch_pass<6, SRC, FIRST, PEAK, 32, V>(c, in, dst, s, pk);
+    case 7: return launch_pass<7, SRC, FIRST, PEAK, 32, V>(c, in, dst, s, pk);
+    case 8: return launch_pass<8, SRC, FIRST, PEAK, 32, V>(c, in, dst, s, pk);
+    }
+    return -1;
+  }
   // a first pass over int16 samples (4 or 2 bytes each) takes 32 columns per workgroup where its tile still fits 64 KiB of LDS
   constexpr bool NARROW = FIRST && (SRC == SRC_IQ || SRC == SRC_REAL16);
   // (tiles of at most 32 KiB -- 8 columns for the later radix-256 passes, radix 128 x 16 columns first -- so that workgroups are
   // short-lived and several fit beside a Viterbi workgroup were measured in the 10 MS/s chain: 36.0-37.2 ms against 34.4-35.8,
   // the decoder no further along when the front end ends; profiles/r03p_chain10M_fft_small_tiles.txt)
   switch (lg) {
-  case 5: return launch_pass<5, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
-  case 6: return launch_pass<6, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
-  case 7: return launch_pass<7, SRC, FIRST, PEAK, NARROW ? 32 : FT>(c, in, dst, s, pk);
-  case 8: return launch_pass<8, SRC, FIRST, PEAK>(c, in, dst, s, pk);
+  case 5: return launch_pass<5, SRC, FIRST, PEAK, NARROW ? 32 : FT, V>(c, in, dst, s, pk);
+  case 6: return launch_pass<6, SRC, FIRST, PEAK, NARROW ? 32 : FT, V>(c, in, dst, s, pk);
+  case 7: return launch_pass<7, SRC, FIRST, PEAK, NARROW ? 32 : FT, V>(c, in, dst, s, pk);
+  case 8: return launch_pass<8, SRC, FIRST, PEAK, FT, V>(c, in, dst, s, pk);
   }
   return -1;
 }
 // forward unnormalised transform of N = 2^logN >= 2^12 points: ceil(logN / 8) LDS-staged passes of 5..8 levels each, the
 // first one reading `in` in the form SRC; ping-pong between out and tmp so that the last pass lands in `out`
 // (pk: the last pass -- never the first: N >= 2^12 takes two -- also leaves per-workgroup peak records)
-template <int SRC>
-static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 *tmp, PeakAsk *pk = nullptr) {
+template <int SRC, typename V = double2>
+static int fft_forward(const FftCtx &c, const FftSrc &in, V *out, V *tmp, PeakAsk *pk = nullptr) {
   const int npass = (c.logN + 7) / 8, base = c.logN / npass, extra = c.logN % npass;
   FftSrc cur = in;
   int s = 1;
@@ -1414,9 +1608,9 @@ static int fft_forward(const FftCtx &c, const FftSrc &in, double2 *out, double2 
     // pass then takes 32 columns = 128-byte read runs): measured at 2^23, 102 + 72 + 67 us against 98 + 73 + 60
     static const bool asc = getenv("ISEE3DSP_FFT_ORDER") && getenv("ISEE3DSP_FFT_ORDER")[0] == 'a';
     const int lg = base + ((asc ? i >= npass - extra : i < extra) ? 1 : 0);
-    double2 *dst = ((npass - 1 - i) & 1) == 0 ? out : tmp;
-    if (pk && i == npass - 1 && i > 0) { if (launch_pass_lg<SRC_C2, false, true>(c, lg, cur, dst, s, pk) != 0) return -1; }
-    else if ((i == 0 ? launch_pass_lg<SRC, true>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false>(c, lg, cur, dst, s)) != 0) return -1;
+    V *dst = ((npass - 1 - i) & 1) == 0 ? out : tmp;
+    if (pk && i == npass - 1 && i > 0) { if (launch_pass_lg<SRC_C2, false, true, V>(c, lg, cur, dst, s, pk) != 0) return -1; }
+    else if ((i == 0 ? launch_pass_lg<SRC, true, false, V>(c, lg, cur, dst, s) : launch_pass_lg<SRC_C2, false, false, V>(c, lg, cur, dst, s)) != 0) return -1;
     cur = FftSrc{dst, nullptr, nullptr, 0}; s <<= lg;
   }
   return 0;
@@ -1474,7 +1668,7 @@ extern "C" void pmd_destroy(void *p) {
   (void)hipStreamSynchronize(h->st); if (h->st && h->own_st) (void)hipStreamDestroy(h->st);
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
-  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red); (void)hipFree(h->d_peakpart);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red); (void)hipFree(h->d_peakpart); (void)hipFree(h->d_dft);
   pin_free(&h->pin_hdr);
   if (h->ev_peak) (void)hipEventDestroy(h->ev_peak);
   if (h->ev_mix) (void)hipEventDestroy(h->ev_mix);
@@ -1518,12 +1712,19 @@ fail:
 // that event and reads the results out of the pinned mailbox.  A caller that alternates two handles on one stream can then
 // have block k+1's transform in the stream before it waits for block k's (cli/pmdemod_core.c), instead of leaving the GPU
 // idle while the host forms Quinn's estimate and the quad-precision carrier parameters.
+static int peak_begin(Pmd *h, int firstbin, int lastbin, bool search);
 extern "C" int pmd_fft_peak_end(void *p, pmd_peak *out) {
   Pmd *h = (Pmd *)p;
   if (!h || !out) return -1;
   CHK(hipSetDevice(h->dev));
   CHK(hipEventSynchronize(h->ev_peak));
   memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
+  if (out->peak == -2) {                 // the search transform could not name the peak for certain: the double transform decides
+    if (peak_begin(h, h->ask_first, h->ask_last, false) != 0) return -1;
+    h->last_path = 2;
+    CHK(hipEventSynchronize(h->ev_peak));
+    memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
+  }
   return 0;
 fail:
   return -1;
@@ -1537,9 +1738,37 @@ extern "C" int pmd_fft_peak_begin(void *p, int firstbin, int lastbin) {
   if (!h) return -1;
   if (firstbin < 0 || lastbin > h->N || firstbin > lastbin) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: bad bin range"); return -1; }
   if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: no block loaded"); return -1; }
+  // ISEE3DSP_FFT_F64=1: the double transform always (its spectrum is then what pmd_get_spectrum copies, without a second run)
+  static const bool f64_only = getenv("ISEE3DSP_FFT_F64") && atoi(getenv("ISEE3DSP_FFT_F64")) != 0;
+  return peak_begin(h, firstbin, lastbin, !h->buf && !f64_only && ((uintptr_t)h->cur_iq & 15u) == 0);
+}
+static int peak_begin(Pmd *h, int firstbin, int lastbin, bool search) {
   CHK(hipSetDevice(h->dev));
+  h->ask_first = firstbin; h->ask_last = lastbin;
+  if (search) {
+    // single-precision search transform (spec / tmp as its ping-pong buffers), candidates, exact bins
+    static const bool force_fb = getenv("ISEE3DSP_FFT_F32_FORCE_FALLBACK") != nullptr;     // test hook
+    const FftCtx c{h->N, h->logN, h->twA, h->twB, h->twR, h->st};
+    const FftSrc in{nullptr, h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip};
+    // the exact bins: every workgroup resident at once (146 VGPRs: three workgroups per CU)
+    int nbd = (h->N / 4 + 255) / 256; if (nbd > 768) nbd = 768;
+    if (grow(&h->d_peakpart, &h->peakpart_cap, sizeof(PeakRec) * (size_t)(h->N / 32 / FT)) != 0 ||
+        grow(&h->d_dft, &h->dft_cap, 256 + sizeof(double2) * 3 * DFT_KMAX * (size_t)RED_BLOCKS) != 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: scratch"); return -1; }
+    PeakAsk ask{firstbin, lastbin, (PeakRec *)h->d_peakpart, 0};
+    h->spec_valid = 0; h->last_path = 1;
+    if (fft_forward<SRC_IQ, float2>(c, in, (float2 *)h->spec, (float2 *)h->tmp, &ask) != 0 || ask.nparts <= 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: FFT launch failed"); return -1; }
+    DftAsk *dask = (DftAsk *)h->d_dft;
+    double2 *dpart = (double2 *)((char *)h->d_dft + 256);
+    k_peak_cands<<<1, 256, 0, h->st>>>(ask.part, ask.nparts, h->N, force_fb ? 1 : 0, dask);
+    k_dft_bins<<<dim3(nbd, DFT_KMAX), 256, 0, h->st>>>((const short2 *)h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip, h->N, h->twA, h->twB, dask, dpart);
+    k_dft_final<<<1, 256, 0, h->st>>>(dpart, nbd, dask, (pmd_peak *)h->pin_hdr.d);
+    CHK(hipGetLastError());
+    CHK(hipEventRecord(h->ev_peak, h->st));
+    return 0;
+  }
   {
     PeakAsk ask{firstbin, lastbin, nullptr, 0};
+    h->spec_valid = 1; h->last_path = 0;
     if (!h->buf) {
       // LDS-staged passes, the first one straight from the int16 block, the last one leaving the peak records
       const FftCtx c{h->N, h->logN, h->twA, h->twB, h->twR, h->st};
@@ -1831,10 +2060,16 @@ fail:
   return -1;
 }
 
+extern "C" int pmd_last_peak_path(void *p) { Pmd *h = (Pmd *)p; return h ? h->last_path : -1; }
 extern "C" int pmd_get_spectrum(void *p, double *out_ri) {
   Pmd *h = (Pmd *)p;
   if (!h) return -1;
   CHK(hipSetDevice(h->dev));
+  if (!h->spec_valid) {                  // the peak search went through the single-precision transform: run the double one now
+    if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_get_spectrum: no block loaded"); return -1; }
+    if (peak_begin(h, h->ask_first, h->ask_last, false) != 0) return -1;
+    CHK(hipEventSynchronize(h->ev_peak));
+  }
   CHK(hipMemcpy(out_ri, h->spec, sizeof(double2) * (size_t)h->N, hipMemcpyDeviceToHost));
   return 0;
 fail:

@@ -8,6 +8,7 @@ here -- FFTW3 missing -- so this parity is UNPINNED, see oracle/pmdemod_oracle.c
 import math
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -161,6 +162,112 @@ def test_pmd_fft_vs_numpy(pkg):
     want = np.fft.fft(iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64))
     assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
     eng.close()
+
+
+def _np_peak(x, first, last):
+    """pmdemod.c:255-279 on numpy's double transform: the LAST maximum of |X|^2 in [first, last) and its neighbours."""
+    X = np.fft.fft(x)
+    e = X.real * X.real + X.imag * X.imag
+    seg = e[first:last]
+    k = first + (len(seg) - 1 - int(np.argmax(seg[::-1])))
+    return k, X
+
+
+def _search_case(kind, N, seed):
+    rng = np.random.default_rng(seed)
+    n = np.arange(N)
+    first, last, lo = 0, N, None
+    if kind == "noise":                   # no carrier at all: the largest of N exponentially distributed bins
+        x = rng.integers(-30000, 30000, N) + 1j * rng.integers(-30000, 30000, N)
+    elif kind == "tone":                  # a carrier between two bins, 10 dB under the noise per sample
+        f = (rng.integers(1, N - 1) + rng.uniform(-0.5, 0.5)) / N
+        x = np.rint(900.0 * np.exp(2j * np.pi * f * n) + rng.normal(0, 2000, N) + 1j * rng.normal(0, 2000, N))
+    elif kind == "range":                 # a strong carrier OUTSIDE the searched bins, a weak one inside
+        x = np.rint(8000.0 * np.exp(2j * np.pi * (N // 8 + 0.3) / N * n) + 300.0 * np.exp(2j * np.pi * (N // 2 + 77.2) / N * n)
+                    + rng.normal(0, 500, N) + 1j * rng.normal(0, 500, N))
+        first, last = N // 2 - 1000, N // 2 + 1000
+    elif kind == "dechirp":               # a chirped carrier, taken out by the LO table (pmdemod.c:232-244)
+        rate = 3.7e-9
+        lo = np.exp(2j * np.pi * 0.5 * rate * n * n)
+        x = np.rint(2500.0 * np.exp(2j * np.pi * ((N // 3 + 0.41) / N * n + 0.5 * rate * n * n))
+                    + rng.normal(0, 1500, N) + 1j * rng.normal(0, 1500, N))
+    elif kind == "edge":                  # the peak at bin 0: its lower neighbour is bin N - 1
+        x = np.rint(3000.0 * np.exp(2j * np.pi * 0.12 / N * n) + rng.normal(0, 800, N) + 1j * rng.normal(0, 800, N))
+    else:
+        raise ValueError(kind)
+    iq = np.empty(2 * N, np.int16)
+    iq[0::2] = np.clip(x.real, -32768, 32767)
+    iq[1::2] = np.clip(x.imag, -32768, 32767)
+    return iq, first, last, lo
+
+
+@pytest.mark.parametrize("kind,lg,seed", [("noise", 16, 1), ("noise", 16, 2), ("noise", 18, 3), ("noise", 20, 4), ("tone", 12, 5),
+                                          ("tone", 16, 6), ("tone", 18, 7), ("tone", 22, 8), ("range", 18, 9), ("dechirp", 18, 10),
+                                          ("edge", 16, 11), ("noise", 13, 12), ("tone", 15, 13), ("noise", 17, 14)])
+def test_pmd_search_transform_names_the_double_transforms_peak(pkg, kind, lg, seed):
+    """The peak search goes through a single-precision transform and evaluates the named bins exactly (include/
+    isee3_dsp_hip.h, pmd_last_peak_path): same bin as the double transform under pmdemod.c's rule, values within 1e-12."""
+    N = 1 << lg
+    iq, first, last, lo = _search_case(kind, N, seed)
+    eng = pkg.PmDemodEngine(N)
+    if lo is not None:
+        eng.set_dechirp(lo)
+    eng.load(iq)
+    pk = eng.fft_peak(first, last)
+    assert eng.last_peak_path() == 1, "the search transform should have named the peak of this block itself"
+    x = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    if lo is not None:
+        x = x * np.conj(lo)
+    k, X = _np_peak(x, first, last)
+    assert pk.peak == k
+    scale = abs(X[k])
+    for got, want in ((complex(pk.peak_re, pk.peak_im), X[k]), (complex(pk.next_re, pk.next_im), X[(k + 1) % N]),
+                      (complex(pk.prev_re, pk.prev_im), X[(k - 1) % N])):
+        assert abs(got - want) <= 1e-12 * scale
+    assert abs(pk.maxenergy - scale * scale) <= 1e-12 * scale * scale
+    # the double transform on request (test hook), and the next peak search is a search again
+    sp = eng.spectrum()
+    assert np.max(np.abs(sp - X)) <= 1e-12 * np.max(np.abs(X))
+    assert eng.fft_peak(first, last).peak == k and eng.last_peak_path() == 1
+    eng.close()
+
+
+def test_pmd_search_transform_falls_back_where_single_precision_cannot_decide(pkg, monkeypatch):
+    """An all-zero block (every bin ties: pmdemod.c's `>=` takes the last one), two tones of equal amplitude (one workgroup
+    of the last pass or two: within 2^-10 of each other either way) and the forced fall-back."""
+    N = 1 << 16
+    eng = pkg.PmDemodEngine(N)
+    eng.load(np.zeros(2 * N, np.int16))
+    pk = eng.fft_peak(100, 5000)
+    assert eng.last_peak_path() == 2 and pk.peak == 4999 and pk.maxenergy == 0.0
+    # two exact tones of equal amplitude: bins a and b tie up to rounding -- whatever the double transform says, goes
+    n = np.arange(N)
+    for a, b in ((1000, 1000 + 256), (1000, 30000)):
+        x = np.rint(4000.0 * (np.exp(2j * np.pi * a / N * n) + np.exp(2j * np.pi * b / N * n)))
+        iq = np.empty(2 * N, np.int16)
+        iq[0::2] = x.real
+        iq[1::2] = x.imag
+        eng.load(iq)
+        pk = eng.fft_peak(0, N)
+        path = eng.last_peak_path()
+        sp = eng.spectrum()
+        e = sp.real * sp.real + sp.imag * sp.imag
+        k = N - 1 - int(np.argmax(e[::-1]))
+        if path == 2:                     # decided by the double transform: exactly its arg-max, exactly its values
+            assert pk.peak == k and pk.peak_re == sp[k].real and pk.peak_im == sp[k].imag
+        else:                             # both bins evaluated exactly (quantisation leaves them ~1e-6 apart): the larger one
+            assert path == 1 and pk.peak in (a, b) and (pk.peak == k or abs(e[a] - e[b]) <= 1e-12 * e[a])
+    eng.close()
+    monkeypatch.setenv("ISEE3DSP_FFT_F32_FORCE_FALLBACK", "1")
+    code = ("import sys; sys.path.insert(0, %r); import importlib, numpy as np\n"
+            "pkg = importlib.import_module('isee3-decoder_amd')\n"
+            "N = 1 << 14; rng = np.random.default_rng(5); iq = rng.integers(-20000, 20000, 2 * N).astype(np.int16)\n"
+            "e = pkg.PmDemodEngine(N); e.load(iq); pk = e.fft_peak(0, N)\n"
+            "X = np.fft.fft(iq[0::2] + 1j * iq[1::2]); p = X.real ** 2 + X.imag ** 2\n"
+            "assert e.last_peak_path() == 2 and pk.peak == N - 1 - int(np.argmax(p[::-1])), (e.last_peak_path(), pk.peak)\n"
+            "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("name", [str(n) for n in np.load(PG)["names"]])
