@@ -126,9 +126,9 @@ int pmd_mix_end(void *h, pmd_mix *res);
 /* How pmd_fft_peak finds the peak (transforms of 2^12 points and more): a SINGLE-precision transform names the bins whose
  * energy lies within 2^-10 of the maximum (normally one), and those bins and their neighbours are then evaluated from the
  * int16 block in double precision, as direct sums -- the values returned are at least as accurate as a double transform's,
- * at under half its memory traffic.  When single precision cannot name the bins for certain (two candidates in one
- * workgroup, more than four in all, an all-zero block) pmd_fft_peak_end runs the double transform instead and its spectrum
- * decides, as before.  ISEE3DSP_FFT_F64=1: always the double transform.
+ * at under half its memory traffic.  When single precision cannot name the bin for certain (a second bin within 2^-10
+ * of the maximum, an all-zero block) pmd_fft_peak_end runs the double transform instead and its spectrum decides, as
+ * before.  ISEE3DSP_FFT_F64=1: always the double transform.
  * pmd_last_peak_path: 0 double transform, 1 search transform + exact bins, 2 search transform, then fallen back. */
 int pmd_last_peak_path(void *h);
 /* test hook: copy the spectrum (fftsize complex doubles) to host (runs the double transform if the peak search did not) */

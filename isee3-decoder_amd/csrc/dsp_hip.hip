@@ -778,6 +778,9 @@ fail:
 // ===========================================================================================
 // pmdemod
 // ===========================================================================================
+#define PIN_DFT 8192       /* 3 x 768 double2 */
+#define PIN_ROT 49152      /* RED_BLOCKS double2 */
+#define PIN_BYTES 65536
 struct Pmd {
   int dev; hipStream_t st; int own_st;
   int N, logN;
@@ -789,13 +792,14 @@ struct Pmd {
   void *d_red; size_t red_cap;           // reduction scratch
   hipEvent_t ev_peak, ev_mix;            // behind the transform + peak kernels / behind the two spin-down passes (the *_begin / *_end calls)
   void *d_peakpart; size_t peakpart_cap; // one peak record per workgroup of the last FFT pass
-  void *d_dft; size_t dft_cap;           // search transform: DftAsk + the partial sums of k_dft_bins
+  int dft_nb, mix_nb;                    // workgroups of the k_dft_bins / k_rotate4 launch in flight (their partial sums are in pin_hdr)
   int ask_first, ask_last;               // the bin range of the peak search in flight (a fall-back repeats it)
   int spec_valid;                        // spec holds the double transform of the current block (pmd_get_spectrum)
   int last_path;                         // pmd_last_peak_path
   int16_t *d_out16; double *d_pre;
   int have_lo;
-  Pin pin_hdr;                           // peak record @0, spin-down sum @128, variance sum @144: written by the kernels
+  Pin pin_hdr;                           // written by the kernels: peak record @0, spin-down sum @128, variance sum @144 (per-sample
+                                         // path), DftStatus @256, k_dft_bins' partial sums @PIN_DFT, k_rotate4's @PIN_ROT
 };
 
 __global__ __launch_bounds__(256) void k_twiddles(double2 *tw, int N) {
@@ -971,7 +975,7 @@ template <typename T> __device__ __forceinline__ bool peak_better(T e, int i, T 
 // FTC: columns per workgroup (FT = 16 everywhere except where the first pass reads 2- or 4-byte samples: there 32 columns
 // make the read runs 128 bytes -- a whole cache line per row and tile -- instead of 64)
 // V = float2 (the search transform): a PEAK pass stores NO spectrum -- its per-workgroup record also says how many of the
-// workgroup's bins lie within PEAK_NEAR of the workgroup's maximum (PeakRec::near), which is what k_peak_cands needs to know
+// workgroup's bins lie within PEAK_NEAR of the workgroup's maximum (PeakRec::near), which is what search_peak needs to know
 // that the records hold EVERY bin near the global maximum.
 #define PEAK_NEAR 9.765625e-4      // 2^-10: relative distance in |X|^2 inside which single precision may have swapped two bins
                                    // (its error against the largest bin is ~1e-6: three orders of margin)
@@ -1305,10 +1309,29 @@ __global__ __launch_bounds__(256) void k_rotate(const short2 *__restrict__ iq, c
 // far inside the 1e-9 the spin-down is held to; after CARRIER_RESEED steps the thread seeds again.  Both kernels run the
 // SAME arithmetic on the same grid, so pass 2 re-forms exactly the products pass 1 summed.
 #define CARRIER_RESEED 64
-__global__ void k_carrier_steps(unsigned long long u_hi, unsigned long long u_lo, double logrho, unsigned long long stride,
-                                double2 *__restrict__ cs) {
+// carrier_1, carrier_2, carrier_3 and carrier_stride: every workgroup forms them itself (four closed-form values; a kernel of
+// their own was one more 5 us launch boundary per block)
+__device__ __forceinline__ void carrier_steps(unsigned long long u_hi, unsigned long long u_lo, double logrho, unsigned long long stride,
+                                              double2 (&cs)[4]) {
+  __shared__ double2 s_cs[4];
   const unsigned t = threadIdx.x;
-  if (t < 4) cs[t] = carrier_at(t < 3 ? (unsigned long long)(t + 1) : stride, u_hi, u_lo, logrho);
+  if (t < 4) s_cs[t] = carrier_at(t < 3 ? (unsigned long long)(t + 1) : stride, u_hi, u_lo, logrho);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) cs[k] = s_cs[k];
+}
+// k_sum2's sum, formed by every workgroup for itself (all 256 threads get it): the same additions in the same order
+__device__ __forceinline__ double2 sum2_block(const double2 *__restrict__ part, int n) {
+  __shared__ double2 ws[256];
+  double sr = 0, si = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { sr += part[i].x; si += part[i].y; }
+  ws[threadIdx.x] = make_double2(sr, si);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ws[threadIdx.x].x += ws[threadIdx.x + o].x; ws[threadIdx.x].y += ws[threadIdx.x + o].y; }
+    __syncthreads();
+  }
+  return ws[0];
 }
 __device__ __forceinline__ void iq_group4(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int g, int flip,
                                           double2 (&v)[4]) {
@@ -1329,9 +1352,11 @@ __device__ __forceinline__ void iq_group4(const short2 *__restrict__ iq, const d
 }
 __global__ __launch_bounds__(256) void k_mix4(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
                                               unsigned long long u_hi, unsigned long long u_lo, double logrho,
-                                              const double2 *__restrict__ cs, double2 *__restrict__ part) {
-  const double2 w1 = cs[0], w2 = cs[1], w3 = cs[2], wT = cs[3];
+                                              double2 *__restrict__ part) {
   const int T = gridDim.x * 256, ng = N >> 2;
+  double2 cs[4];
+  carrier_steps(u_hi, u_lo, logrho, 4ull * (unsigned long long)T, cs);
+  const double2 w1 = cs[0], w2 = cs[1], w3 = cs[2], wT = cs[3];
   double sr = 0, si = 0;
   double2 c0 = make_double2(1.0, 0.0);
   int it = 0;
@@ -1354,15 +1379,19 @@ __global__ __launch_bounds__(256) void k_mix4(const short2 *__restrict__ iq, con
   if (threadIdx.x == 0)
     part[blockIdx.x] = make_double2(ws[0].x + ws[1].x + ws[2].x + ws[3].x, ws[0].y + ws[1].y + ws[2].y + ws[3].y);
 }
-// pass 2; the block sum of pass 1 is read from device memory (dcsum) and turned into conj(dc) / |dc| here (pmdemod.c:337-338),
-// so that no host round trip separates the two passes
+// pass 2; every workgroup adds pass 1's partial sums itself (sum2_block: no kernel and no host round trip between the
+// passes) and turns the total into conj(dc) / |dc| (pmdemod.c:337-338); workgroup 0 also leaves it in the mailbox (dc_out).
+// Its own partial sums (the variance terms) go to pinned host memory: pmd_mix_end adds them (sum2_host)
 __global__ __launch_bounds__(256) void k_rotate4(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
                                                  unsigned long long u_hi, unsigned long long u_lo, double logrho,
-                                                 const double2 *__restrict__ cs, const double2 *__restrict__ dcsum,
+                                                 const double2 *__restrict__ mixpart, double2 *__restrict__ dc_out,
                                                  int16_t *__restrict__ out16, double *__restrict__ pre,
                                                  double2 *__restrict__ part) {
+  double2 cs[4];
+  carrier_steps(u_hi, u_lo, logrho, 4ull * (unsigned long long)gridDim.x * 256ull, cs);
   const double2 w1 = cs[0], w2 = cs[1], w3 = cs[2], wT = cs[3];
-  const double2 dcs = *dcsum;
+  const double2 dcs = sum2_block(mixpart, (int)gridDim.x);      // (k_mix4 ran on the same grid)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dc_out = dcs;
   const double dcr = dcs.x / N, dci = dcs.y / N;
   const double amp = hypot(dcr, dci);
   const double ur = dcr / amp, ui = -dci / amp;
@@ -1404,75 +1433,73 @@ __global__ __launch_bounds__(256) void k_rotate4(const short2 *__restrict__ iq, 
 // pmdemod.c:253-318 needs three numbers of the 2^23-point spectrum: the largest bin (last one on ties) and its two
 // neighbours.  The transform that finds it need not be the one that evaluates it: k_fft_pass<..., float2> moves half the
 // bytes per pass and its last pass stores nothing (302 MB instead of 704 MB of traffic at 2^23), leaving one record per
-// workgroup; k_peak_cands turns the records into the list of bins whose single-precision energy lies within PEAK_NEAR of
-// the maximum (normally one); k_dft_bins evaluates X[k-1], X[k], X[k+1] of every listed bin from the int16 block in DOUBLE
-// precision (stepped twiddles as k_mix4's carriers, seeded from the transform's own table of W_N^m);
-// k_dft_final adds the partial sums in a fixed order and applies pmdemod.c's arg-max rule to the exact energies.  What
-// leaves is at least as accurate as the double transform's bins (a direct sum: ~1e-16 sqrt(N) relative).  The list is
-// COMPLETE by construction: a bin within PEAK_NEAR of the global maximum is within PEAK_NEAR of its own workgroup's maximum,
-// and a workgroup that holds two such bins says so (PeakRec::near > 1).  Then -- or with more than DFT_KMAX candidates, or
-// nothing positive (an all-zero block: every bin ties) -- status = 1 and pmd_fft_peak_end runs the double transform.
-#define DFT_KMAX 4
-struct DftAsk { int status, ncand; int bins[3 * DFT_KMAX]; };        // per candidate: k - 1, k, k + 1 (mod N)
-__global__ __launch_bounds__(256) void k_peak_cands(const PeakRec *__restrict__ part, int nparts, int N, int force_fallback,
-                                                    DftAsk *__restrict__ ask) {
+// workgroup.  k_dft_bins -- every workgroup for itself, the records are 32 KiB -- finds the largest record and checks that it
+// is the ONLY bin whose single-precision energy lies within PEAK_NEAR of the maximum, then evaluates X[k-1], X[k], X[k+1]
+// from the int16 block in DOUBLE precision (stepped twiddles as k_mix4's carriers, seeded from the transform's own table of
+// W_N^m) and leaves one partial sum per workgroup in pinned host memory; pmd_fft_peak_end adds them in a fixed order
+// (sum2_host = k_sum2's order).  What leaves is at least as accurate as the double transform's bins (a direct sum: ~1e-16
+// sqrt(N) relative).  The check is COMPLETE by construction: a bin within PEAK_NEAR of the global maximum is within
+// PEAK_NEAR of its own workgroup's maximum, and a workgroup that holds two such bins says so (PeakRec::near > 1).  Then --
+// or with a second candidate anywhere (1.6 % of carrier-less noise blocks), or nothing positive (an all-zero block: every
+// bin ties) -- status = 1 and pmd_fft_peak_end runs the double transform.  (First form: a candidate-list kernel, up to four
+// candidates and a final-sum kernel -- three launches of 6-7 us each behind the passes instead of one.)
+struct DftStatus { int status, peak; };                    // in pinned host memory: 0 = the partial sums are those of bin `peak`
+// the largest record under pmdemod.c's rule, and whether it stands alone; every thread of a 256-thread workgroup calls it
+__device__ __forceinline__ bool search_peak(const PeakRec *__restrict__ part, int nparts, int *peak) {
   __shared__ PeakRec ws[256];
-  __shared__ int s_n, s_amb, s_bins[DFT_KMAX];
+  __shared__ int s_n;
+  const int tid = (int)threadIdx.x;
   double be = -1.0; int bi = -1;
-  for (int p = threadIdx.x; p < nparts; p += 256) if (peak_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
-  ws[threadIdx.x].e = be; ws[threadIdx.x].idx = bi;
-  if (threadIdx.x == 0) { s_n = 0; s_amb = 0; }
+  for (int p = tid; p < nparts; p += 256) if (peak_better(part[p].e, part[p].idx, be, bi)) { be = part[p].e; bi = part[p].idx; }
+  ws[tid].e = be; ws[tid].idx = bi;
+  if (tid == 0) s_n = 0;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o && peak_better(ws[threadIdx.x + o].e, ws[threadIdx.x + o].idx, ws[threadIdx.x].e, ws[threadIdx.x].idx))
-      ws[threadIdx.x] = ws[threadIdx.x + o];
+    if (tid < o && peak_better(ws[tid + o].e, ws[tid + o].idx, ws[tid].e, ws[tid].idx)) ws[tid] = ws[tid + o];
     __syncthreads();
   }
   be = ws[0].e; bi = ws[0].idx;
   const double lim = be * (1.0 - PEAK_NEAR);
+  int mine = 0;
   if (bi >= 0 && be > 0.0)
-    for (int p = threadIdx.x; p < nparts; p += 256)
-      if (part[p].idx >= 0 && part[p].e >= lim) {
-        const int slot = atomicAdd(&s_n, 1);
-        if (slot < DFT_KMAX) s_bins[slot] = part[p].idx;
-        if (part[p].near > 1) s_amb = 1;
-      }
+    for (int p = tid; p < nparts; p += 256)
+      if (part[p].idx >= 0 && part[p].e >= lim) mine += part[p].near > 1 ? 2 : 1;      // (an ambiguous workgroup counts twice)
+  if (mine) atomicAdd(&s_n, mine);
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  const bool ok = bi >= 0 && be > 0.0 && s_n >= 1 && s_n <= DFT_KMAX && !s_amb && !force_fallback;
-  ask->status = ok ? 0 : 1; ask->ncand = ok ? s_n : 0;
-  for (int j = 0; ok && j < s_n; j++) {
-    const int k = s_bins[j];
-    ask->bins[3 * j] = (N + k - 1) % N; ask->bins[3 * j + 1] = k; ask->bins[3 * j + 2] = (k + 1) % N;
-  }
+  *peak = bi;
+  return bi >= 0 && be > 0.0 && s_n == 1;
 }
-// X[bin] = sum_n sample_n e^{-2 pi j bin n / N} for the three bins of candidate blockIdx.y; one partial sum per workgroup
 // (the twiddles W_N^m come from the transform's own two-level table -- W_N^(4096 h) * W_N^l, both entries correctly rounded
-// -- instead of a sincospi per seed: the first form of this kernel spent two thirds of its 35 us on its 9 sincospi per thread)
+// -- instead of a sincospi per seed)
 __device__ __forceinline__ double2 tw_at(const double2 *__restrict__ twA, const double2 *__restrict__ twB, unsigned m) {
   const double2 wb = twB[m & 4095u], wa = twA[m >> 12];
   return (m >> 12) ? cmul(wa, wb) : wb;
 }
+// X[bin] = sum_n sample_n e^{-2 pi j bin n / N} for bin = peak - 1, peak, peak + 1 (mod N); one partial sum per workgroup
+// and bin: part[b * gridDim.x + blockIdx.x] (pinned host memory)
 __global__ __launch_bounds__(256) void k_dft_bins(const short2 *__restrict__ iq, const double2 *__restrict__ lo, int flip, int N,
                                                   const double2 *__restrict__ twA, const double2 *__restrict__ twB,
-                                                  const DftAsk *__restrict__ ask, double2 *__restrict__ part) {
-  if (ask->status != 0 || (int)blockIdx.y >= ask->ncand) return;
+                                                  const PeakRec *__restrict__ rec, int nrec, int force_fallback,
+                                                  DftStatus *__restrict__ status, double2 *__restrict__ part) {
+  int peak;
+  const bool ok = search_peak(rec, nrec, &peak) && !force_fallback;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { status->status = ok ? 0 : 1; status->peak = peak; }
+  if (!ok) return;
   __shared__ double2 sw[3][4];
   __shared__ double2 wsum[3][4];
   const int T = gridDim.x * 256, ng = N >> 2;
   const unsigned long long nm = (unsigned long long)N - 1ull;
+  unsigned long long u[3] = {(unsigned long long)((N + peak - 1) % N), (unsigned long long)peak, (unsigned long long)((peak + 1) % N)};
   if (threadIdx.x < 12) {
     const int b = threadIdx.x >> 2, j = threadIdx.x & 3;
-    const unsigned long long bin = (unsigned long long)ask->bins[3 * blockIdx.y + b];
+    const unsigned long long bin = b == 0 ? u[0] : b == 1 ? u[1] : u[2];
     sw[b][j] = tw_at(twA, twB, (unsigned)((bin * (j < 3 ? (unsigned long long)(j + 1) : 4ull * (unsigned long long)T)) & nm));
   }
   __syncthreads();
-  unsigned long long u[3];
   double2 w1[3], w2[3], w3[3], wT[3], c0[3];
   double sr[3] = {0, 0, 0}, si[3] = {0, 0, 0};
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    u[b] = (unsigned long long)ask->bins[3 * blockIdx.y + b];
     w1[b] = sw[b][0]; w2[b] = sw[b][1]; w3[b] = sw[b][2]; wT[b] = sw[b][3];
     c0[b] = make_double2(1.0, 0.0);
   }
@@ -1500,40 +1527,22 @@ __global__ __launch_bounds__(256) void k_dft_bins(const short2 *__restrict__ iq,
   __syncthreads();
   if (threadIdx.x < 3) {
     const int b = threadIdx.x;
-    part[((size_t)blockIdx.y * 3 + b) * gridDim.x + blockIdx.x] =
+    part[(size_t)b * gridDim.x + blockIdx.x] =
       make_double2(wsum[b][0].x + wsum[b][1].x + wsum[b][2].x + wsum[b][3].x, wsum[b][0].y + wsum[b][1].y + wsum[b][2].y + wsum[b][3].y);
   }
 }
-// the partial sums in a fixed order; pmdemod.c:255-279's rule (last maximum wins) on the exact energies; out->peak = -2 tells
-// pmd_fft_peak_end to run the double transform
-__global__ __launch_bounds__(256) void k_dft_final(const double2 *__restrict__ part, int nb, const DftAsk *__restrict__ ask, pmd_peak *out) {
-  __shared__ double2 ws[256];
-  __shared__ double2 X[3 * DFT_KMAX];
-  if (ask->status != 0) { if (threadIdx.x == 0) out->peak = -2; return; }
-  const int nc = ask->ncand;
-  for (int v = 0; v < 3 * nc; v++) {
-    double2 a = make_double2(0.0, 0.0);
-    for (int p = threadIdx.x; p < nb; p += 256) { const double2 q = part[(size_t)v * nb + p]; a.x += q.x; a.y += q.y; }
-    ws[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) { ws[threadIdx.x].x += ws[threadIdx.x + o].x; ws[threadIdx.x].y += ws[threadIdx.x + o].y; }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) X[v] = ws[0];
-    __syncthreads();
+// k_sum2's sum on the host: thread t adds elements t, t + 256, ...; then the tree 128, 64, ... 1 -- the same additions in
+// the same order, so a total formed here equals the one k_sum2 (or sum2_block, on the device) forms
+static double2 sum2_host(const volatile double2 *part, int n) {
+  double2 ws[256];
+  for (int t = 0; t < 256; t++) {
+    double sr = 0, si = 0;
+    for (int i = t; i < n; i += 256) { sr += part[i].x; si += part[i].y; }
+    ws[t] = make_double2(sr, si);
   }
-  if (threadIdx.x != 0) return;
-  double be = -1.0; int bi = -1, bc = 0;
-  for (int c = 0; c < nc; c++) {
-    const double2 x = X[3 * c + 1];
-    const double e = x.x * x.x + x.y * x.y;
-    if (peak_better(e, ask->bins[3 * c + 1], be, bi)) { be = e; bi = ask->bins[3 * c + 1]; bc = c; }
-  }
-  out->peak = bi; out->maxenergy = be;
-  out->peak_re = X[3 * bc + 1].x; out->peak_im = X[3 * bc + 1].y;
-  out->next_re = X[3 * bc + 2].x; out->next_im = X[3 * bc + 2].y;
-  out->prev_re = X[3 * bc].x;     out->prev_im = X[3 * bc].y;
+  for (int o = 128; o > 0; o >>= 1)
+    for (int t = 0; t < o; t++) { ws[t].x += ws[t + o].x; ws[t].y += ws[t + o].y; }
+  return ws[0];
 }
 
 // what a transform needs besides its data: the twiddle tables of its size and a stream
@@ -1573,6 +1582,8 @@ template <int SRC, bool FIRST, bool PEAK = false, typename V = double2>
 static int launch_pass_lg(const FftCtx &c, int lg, const FftSrc &in, V *dst, int s, PeakAsk *pk = nullptr) {
   // the search transform (8-byte elements): 32 columns everywhere -- 256-byte runs, 64 KiB tiles at radix 256
   if constexpr (std::is_same<V, float2>::value) {
+    // (16 columns -- 32 KiB tiles, four or five workgroups per CU -- measured the same: 29 + 26 + 24 us against 28 + 27 + 26 at
+    // 2^23, and twice the records for k_dft_bins; profiles/r03ak_*)
     switch (lg) {
     case 5: return launch_pass<5, SRC, FIRST, PEAK, 32, V>(c, in, dst, s, pk);
     case 6: return launch_pass<6, SRC, FIRST, PEAK, 32, V>(c, in, dst, s, pk);
@@ -1643,7 +1654,7 @@ extern "C" void *pmd_create(int fftsize) {
   CHK(hipMalloc(&h->d_pre, sizeof(double) * (size_t)fftsize));
   h->red_cap = sizeof(double2) * (RED_BLOCKS + 64) + sizeof(pmd_peak) + sizeof(PeakRec) * RED_BLOCKS;
   CHK(hipMalloc(&h->d_red, h->red_cap));
-  if (pin_grow(&h->pin_hdr, 256) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: pinned mailbox"); goto fail; }
+  if (pin_grow(&h->pin_hdr, PIN_BYTES) != 0) { snprintf(g_err, sizeof g_err, "pmd_create: pinned mailbox"); goto fail; }
   CHK(hipEventCreateWithFlags(&h->ev_peak, hipEventDisableTiming));
   CHK(hipEventCreateWithFlags(&h->ev_mix, hipEventDisableTiming));
   if (lg >= 12 && !getenv("ISEE3DSP_FFT_REGISTER_RADIX")) {
@@ -1668,7 +1679,7 @@ extern "C" void pmd_destroy(void *p) {
   (void)hipStreamSynchronize(h->st); if (h->st && h->own_st) (void)hipStreamDestroy(h->st);
   (void)hipFree(h->buf); (void)hipFree(h->spec); (void)hipFree(h->tmp); (void)hipFree(h->tw); (void)hipFree(h->lo);
   (void)hipFree(h->twA); (void)hipFree(h->twB); (void)hipFree(h->twR);
-  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red); (void)hipFree(h->d_peakpart); (void)hipFree(h->d_dft);
+  (void)hipFree(h->d_iq); (void)hipFree(h->d_out16); (void)hipFree(h->d_pre); (void)hipFree(h->d_red); (void)hipFree(h->d_peakpart);
   pin_free(&h->pin_hdr);
   if (h->ev_peak) (void)hipEventDestroy(h->ev_peak);
   if (h->ev_mix) (void)hipEventDestroy(h->ev_mix);
@@ -1718,13 +1729,21 @@ extern "C" int pmd_fft_peak_end(void *p, pmd_peak *out) {
   if (!h || !out) return -1;
   CHK(hipSetDevice(h->dev));
   CHK(hipEventSynchronize(h->ev_peak));
-  memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
-  if (out->peak == -2) {                 // the search transform could not name the peak for certain: the double transform decides
+  if (h->last_path == 1) {               // search transform: the exact bins' partial sums are in the mailbox
+    const volatile DftStatus *st = (const volatile DftStatus *)((char *)h->pin_hdr.h + 256);
+    if (st->status == 0) {
+      const volatile double2 *part = (const volatile double2 *)((char *)h->pin_hdr.h + PIN_DFT);
+      const double2 xp = sum2_host(part, h->dft_nb), xk = sum2_host(part + h->dft_nb, h->dft_nb), xn = sum2_host(part + 2 * h->dft_nb, h->dft_nb);
+      out->peak = st->peak; out->maxenergy = xk.x * xk.x + xk.y * xk.y;
+      out->peak_re = xk.x; out->peak_im = xk.y; out->next_re = xn.x; out->next_im = xn.y; out->prev_re = xp.x; out->prev_im = xp.y;
+      return 0;
+    }
+    // single precision could not name the peak for certain: the double transform decides
     if (peak_begin(h, h->ask_first, h->ask_last, false) != 0) return -1;
     h->last_path = 2;
     CHK(hipEventSynchronize(h->ev_peak));
-    memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
   }
+  memcpy(out, h->pin_hdr.h, sizeof(pmd_peak));
   return 0;
 fail:
   return -1;
@@ -1751,17 +1770,14 @@ static int peak_begin(Pmd *h, int firstbin, int lastbin, bool search) {
     const FftCtx c{h->N, h->logN, h->twA, h->twB, h->twR, h->st};
     const FftSrc in{nullptr, h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip};
     // the exact bins: every workgroup resident at once (146 VGPRs: three workgroups per CU)
-    int nbd = (h->N / 4 + 255) / 256; if (nbd > 768) nbd = 768;
-    if (grow(&h->d_peakpart, &h->peakpart_cap, sizeof(PeakRec) * (size_t)(h->N / 32 / FT)) != 0 ||
-        grow(&h->d_dft, &h->dft_cap, 256 + sizeof(double2) * 3 * DFT_KMAX * (size_t)RED_BLOCKS) != 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: scratch"); return -1; }
+    int nbd = (h->N / 4 + 255) / 256; if (nbd > 768) nbd = 768;         // (256 .. 768 workgroups measured the same; PIN_DFT holds 768)
+    if (grow(&h->d_peakpart, &h->peakpart_cap, sizeof(PeakRec) * (size_t)(h->N / 32 / FT)) != 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: scratch"); return -1; }
     PeakAsk ask{firstbin, lastbin, (PeakRec *)h->d_peakpart, 0};
     h->spec_valid = 0; h->last_path = 1;
     if (fft_forward<SRC_IQ, float2>(c, in, (float2 *)h->spec, (float2 *)h->tmp, &ask) != 0 || ask.nparts <= 0) { snprintf(g_err, sizeof g_err, "pmd_fft_peak: FFT launch failed"); return -1; }
-    DftAsk *dask = (DftAsk *)h->d_dft;
-    double2 *dpart = (double2 *)((char *)h->d_dft + 256);
-    k_peak_cands<<<1, 256, 0, h->st>>>(ask.part, ask.nparts, h->N, force_fb ? 1 : 0, dask);
-    k_dft_bins<<<dim3(nbd, DFT_KMAX), 256, 0, h->st>>>((const short2 *)h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip, h->N, h->twA, h->twB, dask, dpart);
-    k_dft_final<<<1, 256, 0, h->st>>>(dpart, nbd, dask, (pmd_peak *)h->pin_hdr.d);
+    h->dft_nb = nbd;
+    k_dft_bins<<<nbd, 256, 0, h->st>>>((const short2 *)h->cur_iq, h->have_lo ? h->lo : nullptr, h->cur_flip, h->N, h->twA, h->twB, ask.part, ask.nparts,
+                                       force_fb ? 1 : 0, (DftStatus *)((char *)h->pin_hdr.d + 256), (double2 *)((char *)h->pin_hdr.d + PIN_DFT));
     CHK(hipGetLastError());
     CHK(hipEventRecord(h->ev_peak, h->st));
     return 0;
@@ -1819,7 +1835,7 @@ extern "C" int pmd_mix_begin(void *p, double cstep, int16_t *out16, double *pre,
   if (!h->cur_iq) { snprintf(g_err, sizeof g_err, "pmd_mix_quantise: no block loaded"); return -1; }
   CHK(hipSetDevice(h->dev));
   {
-    double2 *part = (double2 *)h->d_red, *tot = part + RED_BLOCKS;
+    double2 *part = (double2 *)h->d_red;
     const short2 *iq = (const short2 *)h->cur_iq;
     const double2 *lo = h->have_lo ? h->lo : nullptr;
     int16_t *o16v = (out16 && out_is_dev) ? out16 : h->d_out16;
@@ -1830,12 +1846,10 @@ extern "C" int pmd_mix_begin(void *p, double cstep, int16_t *out16, double *pre,
     pmd_carrier_params(cstep, &u_hi, &u_lo, &logrho);
     // stepped carrier, four samples per thread and step, both passes and their sums without a host round trip in between
     int nb4 = (h->N / 4 + 255) / 256; if (nb4 > RED_BLOCKS) nb4 = RED_BLOCKS;
-    double2 *cs = tot + 8;
-    k_carrier_steps<<<1, 64, 0, h->st>>>(u_hi, u_lo, logrho, 4ull * (unsigned long long)nb4 * 256ull, cs);
-    k_mix4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, part);
-    k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 128), tot);
-    k_rotate4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, cs, tot, o16v, oprev, part);
-    k_sum2<<<1, 256, 0, h->st>>>(part, nb4, (double2 *)((char *)h->pin_hdr.d + 144));
+    h->mix_nb = nb4;
+    k_mix4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, part);
+    k_rotate4<<<nb4, 256, 0, h->st>>>(iq, lo, h->cur_flip, h->N, u_hi, u_lo, logrho, part, (double2 *)((char *)h->pin_hdr.d + 128), o16v, oprev,
+                                      (double2 *)((char *)h->pin_hdr.d + PIN_ROT));
     CHK(hipGetLastError());
     if (out16 && !out_is_dev) CHK(hipMemcpyAsync(out16, h->d_out16, sizeof(int16_t) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
     if (pre && !out_is_dev) CHK(hipMemcpyAsync(pre, h->d_pre, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, h->st));
@@ -1853,7 +1867,8 @@ extern "C" int pmd_mix_end(void *p, pmd_mix *res) {
   {
     const volatile double *m = (const volatile double *)((char *)h->pin_hdr.h + 128);
     const double dcr = m[0] / h->N, dci = m[1] / h->N;
-    res->dc_re = dcr; res->dc_im = dci; res->amplitude = hypot(dcr, dci); res->diffsumsq = m[2] / h->N;
+    const double2 var = sum2_host((const volatile double2 *)((char *)h->pin_hdr.h + PIN_ROT), h->mix_nb);
+    res->dc_re = dcr; res->dc_im = dci; res->amplitude = hypot(dcr, dci); res->diffsumsq = var.x / h->N;
   }
   return 0;
 fail:

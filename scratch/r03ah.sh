@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: launches folded into their producers (last_block_arrives): DSP tests, transform timing with a kernel trace, chains
+# round 3: the small kernels of a pmdemod block removed (per-workgroup sums, final sums on the host): DSP tests, transform timing with a kernel trace, chains
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 OUT=gpurun_out/r03ah; rm -rf $OUT; mkdir -p $OUT
