@@ -428,11 +428,15 @@ typedef struct { vdecode_opts o; int fd_in; FILE *out; int rc; double ms; volati
 static void *pm_thread(void *p) {
   pm_arg *a = p;
   pmdemod_engine e = { pm_create, pm_dechirp, pm_load, pm_peak, pm_mix, pm_destroy, pm_load_dev, pm_mix_dev, NULL, NULL, NULL, NULL };
-  /* ISEE3_CHAIN_PM_PIPELINE=1: two pmdemod handles in turn, block k+1's transform enqueued before block k's peak is awaited
-   * (pmdemod_core.h).  Measured: pmdemod's engine time 6.0 -> 2.9 ms at 250 kS/s -- and the chain not a bit faster at either
-   * rate (its front end is paced by symdemod's windows and by the decoders on the same CUs), 7 % slower from a capture in
-   * pageable host memory (the next block's staged H2D copy queues in front of this block's spin-down).  Off by default. */
-  if (getenv("ISEE3_CHAIN_PM_PIPELINE") && atoi(getenv("ISEE3_CHAIN_PM_PIPELINE"))) {
+  /* Two pmdemod handles in turn, block k+1's transform enqueued before block k's peak is awaited (pmdemod_core.h): on for a
+   * capture that lies in device memory, off for one in host memory (there the next block's staged H2D copy queues in front
+   * of this block's spin-down: 7 % slower); ISEE3_CHAIN_PM_PIPELINE=0 / 1 overrides.  Measured with six launches per block
+   * (profiles/r03ar_*): pmdemod's engine time 17.8 -> 14-15 ms at 10 MS/s, chain 14.51-14.65 -> 14.72-14.82 Gsamples/s;
+   * 5.6 -> 2.3 ms at 250 kS/s, chain the same (its front end is paced by symdemod's windows).  (With eleven launches per
+   * block and the double transform the chain had gained nothing at either rate: profiles/r03z_*.) */
+  int pipeline = a->src.is_dev && !a->src.f;
+  if (getenv("ISEE3_CHAIN_PM_PIPELINE")) pipeline = atoi(getenv("ISEE3_CHAIN_PM_PIPELINE")) != 0;
+  if (pipeline) {
     e.fft_peak_begin = pm_peak_begin; e.fft_peak_end = pm_peak_end; e.mix_begin = pm_mix_begin; e.mix_end = pm_mix_end;
   }
   pmdemod_source src = { iq_next, &a->src };

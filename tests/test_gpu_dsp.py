@@ -285,6 +285,21 @@ def test_pmdemod_cli_vs_oracle(pkg, name):
     assert len(bad) <= max(2, len(ref) // 100000)
 
 
+@pytest.mark.parametrize("name", [str(n) for n in np.load(PG)["names"]])
+def test_pmdemod_cli_same_samples_whichever_transform_finds_the_peak(pkg, name, monkeypatch):
+    """The stage's int16 output with the single-precision search transform (default) and with the double transform
+    (ISEE3DSP_FFT_F64=1): Quinn's three bins are double-precision values either way, so the carrier estimates agree to
+    ~1e-13 and the samples may differ by one LSB only where the value sits on an integer boundary."""
+    z = np.load(PG)
+    args, iq = _pm_args(z[name + "/cfg"]), z[name + "/iq"].tobytes()
+    a = np.frombuffer(_run(pkg.cli_path("pmdemod"), args, iq), np.int16)
+    monkeypatch.setenv("ISEE3DSP_FFT_F64", "1")
+    b = np.frombuffer(_run(pkg.cli_path("pmdemod"), args, iq), np.int16)
+    assert len(a) == len(b)
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    assert d.max(initial=0) <= 1 and np.count_nonzero(d) <= max(2, len(a) // 100000)
+
+
 def test_full_chain_cli(pkg):
     """pmdemod | symdemod | vdecode on a synthetic PM capture recovers the sent telemetry bits."""
     fs = 32768.0
