@@ -667,7 +667,10 @@ fail:
 // outside the tables, a gain the device rounds differently from the host, or sums outside the exact range make the call
 // return 1 and change nothing: the caller then takes the step-by-step calls for that window.
 struct WinHdr { int bi; int miss; double best; double gain; unsigned inexact; unsigned pad; };
-__global__ __launch_bounds__(256) void k_ts_argmax(const double *__restrict__ en, int noff, WinHdr *__restrict__ hdr) {
+// the first maximum of the offsets' energies (symdemod.c:326-331: strict '>'); every thread of a 256-thread workgroup calls it
+// and gets the result.  k_window_demod's few workgroups each do it for themselves: as a kernel of its own (k_ts_argmax, one
+// workgroup) it was 18 us per window at 10 MS/s, most of it the launch.
+__device__ __forceinline__ void ts_argmax(const double *__restrict__ en, int noff, int *out_bi, double *out_best) {
   __shared__ double wv[256]; __shared__ int wi[256];
   double be = 0; int bi = -1;
   for (int t = threadIdx.x; t < noff; t += 256) {                    // ascending t per thread: strict '>' keeps the first maximum
@@ -684,19 +687,20 @@ __global__ __launch_bounds__(256) void k_ts_argmax(const double *__restrict__ en
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { hdr->bi = wi[0]; hdr->best = wv[0]; hdr->miss = 0; }
+  *out_bi = wi[0]; *out_best = wv[0];
 }
 __global__ __launch_bounds__(256) void k_window_demod(const long long *__restrict__ P, const int *__restrict__ tables, int ne,
                                                       int first_off, int spec_lo, int nspec, const unsigned char *__restrict__ table_ok,
-                                                      int symbolclocks, int nsymbols, const WinHdr *__restrict__ hdr,
+                                                      int symbolclocks, int nsymbols, const double *__restrict__ en, int noff,
                                                       const unsigned *__restrict__ inexact, uint8_t *__restrict__ out,
                                                       WinHdr *__restrict__ host_hdr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int bi = hdr->bi, j = bi + first_off - spec_lo;
-  const double best = hdr->best;
+  int bi; double best;
+  ts_argmax(en, noff, &bi, &best);
+  const int j = bi + first_off - spec_lo;
   const double maxenergy = best / (double)nsymbols;                  // symdemod.c:333
   const double gain = 100. / sqrt(maxenergy);                        // :190
-  const bool miss = j < 0 || j >= nspec || !table_ok[j < 0 || j >= nspec ? 0 : j];
+  const bool miss = bi < 0 || j < 0 || j >= nspec || !table_ok[j < 0 || j >= nspec ? 0 : j];
   if (i == 0) { host_hdr->bi = bi; host_hdr->best = best; host_hdr->gain = gain; host_hdr->miss = miss ? 1 : 0;
                 host_hdr->inexact = inexact ? *inexact : 0u; }
   if (miss || i >= nsymbols) return;
@@ -741,7 +745,6 @@ extern "C" int symd_window(void *p, int firstsample, const int *sw, int symbolcl
     const int *d_sw = (const int *)h->d_idx, *d_tab = d_sw + nsw;
     const unsigned char *d_ok = (const unsigned char *)(d_sw + tab_ints);
     double *d_en = (double *)h->d_e;
-    WinHdr *d_hdr = (WinHdr *)((char *)h->d_e + sizeof(double) * (size_t)noff);
     WinHdr *host_hdr_d = (WinHdr *)((char *)h->pin_hdr.d + 64);
     volatile WinHdr *host_hdr = (volatile WinHdr *)((char *)h->pin_hdr.h + 64);
     const int nslices = (nsymbols + TS_SLICE - 1) / TS_SLICE;
@@ -753,9 +756,8 @@ extern "C" int symd_window(void *p, int firstsample, const int *sw, int symbolcl
                                                                             (unsigned long long *)h->d_part, h->d_flag);
       k_timesearch_fin<<<(noff + 255) / 256, 256, 0, h->st>>>((const unsigned long long *)h->d_part, nslices, noff, d_en, h->d_flag);
     } else if (launch_ordered_search(h, lo, d_sw, symbolclocks, nsymbols, noff, d_en) != 0) goto fail;
-    k_ts_argmax<<<1, 256, 0, h->st>>>(d_en, noff, d_hdr);
     k_window_demod<<<(nsymbols + 255) / 256, 256, 0, h->st>>>(h->d_P, d_tab, nsw, first_off, spec_lo, nspec, d_ok, symbolclocks, nsymbols,
-                                                              d_hdr, exact_form ? h->d_flag : nullptr, (uint8_t *)h->pin_out.d, host_hdr_d);
+                                                              d_en, noff, exact_form ? h->d_flag : nullptr, (uint8_t *)h->pin_out.d, host_hdr_d);
     CHK(hipGetLastError());
     CHK(hipStreamSynchronize(h->st));
     const unsigned flag = exact_form ? host_hdr->inexact : 1u;
