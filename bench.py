@@ -385,7 +385,7 @@ def segmented_record(a, ctx, iq, sent, fs, binsize, nseg, warm_blocks, steps, wa
             view.ptr = None
 
     def step():
-        out["parts"] = harness.run_segments(plan, mine, run_one, concurrency=2)
+        out["parts"] = harness.run_segments(plan, mine, run_one, concurrency=a.segment_concurrency)
 
     dd = dist if world > 1 else None
     fence = harness.make_fence(dd, torch.cuda.synchronize)
@@ -404,9 +404,9 @@ def segmented_record(a, ctx, iq, sent, fs, binsize, nseg, warm_blocks, steps, wa
             "scaling": "strong",
             "config": {"workload": "ONE capture of %d blocks of 2^%d samples (%.1f s of %g kS/s int16 IQ, %g Hz bins, full-band "
                                    "carrier search) cut into %d overlapped block-aligned segments (%d after merging those that "
-                                   "start at block 0), warm-up %d blocks, segment g -> rank g mod %d, two chains at a time per "
+                                   "start at block 0), warm-up %d blocks, segment g -> rank g mod %d, %d chains at a time per "
                                    "GPU, capture resident in HBM, stitched on rank 0"
-                                   % (nblocks, int(np.log2(N)), nsamp / fs, fs / 1e3, binsize, nseg, len(plan), warm_blocks, world),
+                                   % (nblocks, int(np.log2(N)), nsamp / fs, fs / 1e3, binsize, nseg, len(plan), warm_blocks, world, a.segment_concurrency),
                        "decoded_bits": nbits, "segments": len(plan), "seams": seams,
                        "samples_processed_incl_overlap": processed,
                        "processed_rate_Msamples_per_s": round(processed * steps / dt / 1e6, 3)},
@@ -524,6 +524,8 @@ def main():
                     help="blocks of 2^23 samples in the stress capture (64 B: every one of the 64 segments owns B blocks and carries 7 "
                          "warm-up blocks; B = 2: 107 s of signal, 4.3 GB)")
     ap.add_argument("--stress-segments", type=int, default=64)
+    ap.add_argument("--segment-concurrency", type=int, default=2,
+                    help="chains that run at the same time on one GPU in the segmented (stress / --chain-segments) form")
     ap.add_argument("--dry-ranks", action="store_true",
                     help="no device work: every rank runs a stand-in step through the same launcher / sharding / fence / MAX "
                          "code on gloo and rank 0 prints the line (CPU test of the N-rank path)")
