@@ -268,7 +268,7 @@ static int vd_whole(void *h, const unsigned char *s, long long n, int d, unsigne
  * as the symbols reach it -- ONE warm-up per capture instead of one per shared block, and both decoders busy for the second
  * half of the front end's run as well (measured, scratch/starve.py: a second busy decoder slows pmdemod / symdemod by 25 %,
  * not more, once every busy stream has its own compute pipe). */
-#define VD_PROG_WARM (2 * CHAIN_CHUNK)       /* seam window (one chunk >= the decode delay of 200) + one chunk of forgetting */
+#define VD_PROG_WARM (2 * g_chunk)           /* seam window (one chunk >= the decode delay of 200) + one chunk of forgetting */
 static int vd_prog_feed_any(vd_ctx *c, const unsigned char *s, int n, int d) {
   if (!c->prog) {
     if (c->expected >= 4 * VD_SHARE_WARM && !c->d[1]) {
