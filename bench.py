@@ -12,8 +12,9 @@ BASELINE.json's metric has two halves; the ONE JSON line rank 0 prints carries b
   "chain"    "end-to-end IQ Msamples/s" on BASELINE configs[2] / [3]: 60 s x 250 kS/s synthetic int16 IQ per GPU through
              pmdemod | symdemod | vdecode in one process (libisee3chain.so), capture resident in HBM
              (isee3_chain_run_dev); the rate with the capture in host memory (PCIe included) rides along.
-  "stress"   BASELINE configs[4]: 10 MS/s, 1 Hz bins (N = 2^23), ONE 64-block capture cut into 64 overlapped segments dealt
-             to the ranks, stitched on rank 0 with every seam verified (strong scaling).
+  "stress"   BASELINE configs[4]: 10 MS/s, 1 Hz bins (N = 2^23), ONE capture of --stress-blocks (128) blocks cut into 64
+             overlapped segments dealt to the ranks (--segment-concurrency = 2 chains at a time per GPU), stitched on rank 0
+             with every seam verified (strong scaling).
 
 N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process
 (before anything here touches a device); one rank per GPU, RCCL only for the barrier / MAX / SUM / the gather of decoded
