@@ -911,9 +911,6 @@ __global__ __launch_bounds__(256) void k_fft_radix(const double2 *__restrict__ x
 // The first stage reads the int16 (I, Q) pairs themselves (pmdemod.c:209-229, de-chirp :237-243 included): the block is
 // never expanded to doubles in memory.
 #define FT 16
-#ifndef FFT1_ABL
-#define FFT1_ABL 0        // bench builds only, first pass: 1 no global loads, 2 no twiddle walk, 4 no stores, 8 no register DFTs
-#endif
 // the passes exist in two element types: double2 (every transform whose values are used) and float2 (pmdemod's SEARCH
 // transform, which only has to find the bins worth evaluating exactly: pmd_fft_peak_begin)
 template <typename V> struct VecOf;
@@ -995,7 +992,7 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
   const int t = blockIdx.x * FTC + c, stride = N / R;
   if (r < R2) {                                           // ---- step 1, thread (c, a = r)
     V v[R1];
-    if constexpr (SRC == SRC_IQ && !(FIRST && (FFT1_ABL & 1))) {
+    if constexpr (SRC == SRC_IQ) {
       // all R1 loads first, then the conversions: written per sample (iq_sample: load, test `lo`, convert) the compiler
       // waited for every load before issuing the next -- sixteen dependent memory round trips, 45 of the pass's 74 us
       short2 raw[R1];
@@ -1035,13 +1032,12 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
 #pragma unroll
     for (int b = 0; b < R1; b++) {
       const int i = t + (r + R2 * b) * stride;
-      if constexpr (FIRST && (FFT1_ABL & 1)) v[b] = mkv<V>((T)(i & 1023), (T)(i >> 10));
-      else if constexpr (SRC == SRC_IQ) v[b] = vec_as<V>(iq_sample(iq, lo, i, flip));
+      if constexpr (SRC == SRC_IQ) v[b] = vec_as<V>(iq_sample(iq, lo, i, flip));
       else if constexpr (SRC == SRC_REAL16) v[b] = mkv<V>(i < flip ? (T)reinterpret_cast<const int16_t *>(iq)[i] : (T)0, (T)0);   // flip = nvalid
       else if constexpr (SRC == SRC_CONJPROD) { const double2 p = cmul(as_d2(x[i]), lo[i]); v[b] = mkv<V>((T)p.x, (T)-p.y); }
       else v[b] = x[i];
     }
-    if constexpr (!(FIRST && (FFT1_ABL & 8))) dft_regs<R1>(v);
+    dft_regs<R1>(v);
 #pragma unroll
     for (int k1 = 0; k1 < R1; k1++) {
       V val = v[brev(k1, lg2c(R1))];
@@ -1061,7 +1057,7 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
     V u[R2];
 #pragma unroll
     for (int a = 0; a < R2; a++) u[a] = Z[(a * R1 + r) * FTC + c];
-    if constexpr (!(FIRST && (FFT1_ABL & 8))) dft_regs<R2>(u);
+    dft_regs<R2>(u);
     const int q = t & (s - 1), ps = t - q;
     V *__restrict__ out = y + q + (size_t)R * ps;
     // stage twiddle W_N^(ps k), k = k1 + R1 k2 (ps k < N), from the two-level table W_N^(4096 h) * W_N^l.  In the first
@@ -1072,9 +1068,8 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
     // lookups are loaded before the first use (four loads in flight instead of four dependent round trips).
     auto tw2_sel = [&](unsigned idx, double2 wb, double2 wa) { return vec_as<V>((idx >> 12) ? cmul(wa, wb) : wb); };
     if constexpr (FIRST) {
-      const bool walk = !(FFT1_ABL & 2);                    // first stage <=> s == 1
-      V wk = mkv<V>((T)1, (T)0), wstep = wk;
-      if (walk) {
+      V wk = mkv<V>((T)1, (T)0), wstep = wk;                // first stage <=> s == 1
+      {
         const unsigned i1 = (unsigned)ps * (unsigned)r, i2 = (unsigned)ps * (unsigned)R1;
         const double2 b1 = twB[i1 & 4095u], a1 = twA[i1 >> 12], b2 = twB[i2 & 4095u], a2 = twA[i2 >> 12];
         if (ps != 0) { wk = tw2_sel(i1, b1, a1); wstep = tw2_sel(i2, b2, a2); }
@@ -1083,20 +1078,17 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
       for (int k2 = 0; k2 < R2; k2++) {
         const int k = r + R1 * k2;
         V val = u[brev(k2, lg2c(R2))];
-        if (walk && ps != 0 && k != 0) val = cmul(val, wk);
-        if (walk) wk = cmul(wk, wstep);
+        if (ps != 0 && k != 0) val = cmul(val, wk);
+        wk = cmul(wk, wstep);
         u_first[k2] = val;                                  // parked: leaves through the LDS transpose below
       }
     } else {
       // later stages: ONE ps per tile.  W^(ps k), k = k1 + R1 k2, is walked like the first stage's: two table lookups
       // (W^(ps k1), W^(ps R1)) and R2 products instead of 2 R2 dependent lookups (the compiler waited for each one: up to
-      // 32 L2 round trips per thread); <= 15 products deep, ~1e-15 relative.  FFT_LOOKUP_ALL=1 (bench builds) keeps the
-      // value-by-value lookups.
-#ifndef FFT_LOOKUP_ALL
-#define FFT_LOOKUP_ALL 0
-#endif
+      // 32 L2 round trips per thread); <= 15 products deep, ~1e-15 relative (measured against the value-by-value lookups:
+      // profiles/r03x_*).
       V wk = mkv<V>((T)1, (T)0), wstep = wk;
-      if (!FFT_LOOKUP_ALL) {
+      {
         const unsigned i1 = (unsigned)ps * (unsigned)r, i2 = (unsigned)ps * (unsigned)R1;
         const double2 b1 = twB[i1 & 4095u], a1 = twA[i1 >> 12], b2 = twB[i2 & 4095u], a2 = twA[i2 >> 12];
         if (ps != 0) { wk = tw2_sel(i1, b1, a1); wstep = tw2_sel(i2, b2, a2); }
@@ -1105,15 +1097,8 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
       for (int k2 = 0; k2 < R2; k2++) {
         const int k = r + R1 * k2;
         V val = u[brev(k2, lg2c(R2))];
-        if (ps != 0 && k != 0) {
-          if (FFT_LOOKUP_ALL) {
-            const unsigned idx = (unsigned)ps * (unsigned)k;
-            double2 w = twB[idx & 4095u];
-            if (idx >> 12) w = cmul(twA[idx >> 12], w);
-            val = cmul(val, vec_as<V>(w));
-          } else val = cmul(val, wk);
-        }
-        if (!FFT_LOOKUP_ALL) wk = cmul(wk, wstep);
+        if (ps != 0 && k != 0) val = cmul(val, wk);
+        wk = cmul(wk, wstep);
         if constexpr (!(PEAK && SEARCH)) out[(size_t)k * s] = val;
         if constexpr (PEAK) {
           const int i = q + R * ps + k * s;                 // the bin this value is (the last pass: N fits an int)
@@ -1143,8 +1128,7 @@ void k_fft_pass(const V *__restrict__ x, const short2 *__restrict__ iq, const do
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < FTC * R; idx += TH) {
       const V o = Z[(idx / R) * (R + 1) + (idx % R)];
-      if constexpr (FFT1_ABL & 4) { if (o.x == (T)1.2345e30) blk[idx] = o; }
-      else blk[idx] = o;
+      blk[idx] = o;
     }
   }
   if constexpr (PEAK) {
