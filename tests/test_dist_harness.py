@@ -167,3 +167,25 @@ def test_bench_record_helpers_without_a_device():
     with bench.pinned_to_one_core() as pin:
         assert not pin.ok or os.sched_getaffinity(0) == {pin.core}
     assert len(os.sched_getaffinity(0)) == h["nproc_allowed"]
+
+
+def test_bench_pmc_constants_match_the_committed_kernel_record():
+    """The VALU-issue roofline of the headline is formed with constants from profiles/r03_pmc_lds15.json: the file must name the
+    kernel the bench times, carry both numbers, and the bytes must be what its own FETCH / WRITE entries add up to
+    (FETCH_SIZE x 2 on gfx950, KiB -> bytes)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pmc, src = bench.pmc_constants("k_acs_lds15")
+    assert src == "profiles/r03_pmc_lds15.json"
+    assert 1000 < pmc["valu_insts_per_wave"] < 1500 and 3.5 < pmc["valu_cycles_per_inst"] < 5.0
+    want = int((2 * pmc["fetch_size_kb_raw"] + pmc["write_size_kb"]) * 1024)
+    assert abs(pmc["hbm_bytes_per_launch"] - want) <= 1024
+    # one read + one write of the 2^23 u16 metrics + 15 decision rows of 1 MiB is the least a 15-step launch can move
+    assert pmc["hbm_bytes_per_launch"] >= 2 * (1 << 24) + 15 * (1 << 20)
+    assert bench.pmc_constants("no_such_kernel") == ({}, None)
+    # the segmented form's concurrency is an argument with the measured default
+    import subprocess, sys
+    h = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120).stdout
+    assert "--segment-concurrency" in h
